@@ -1,0 +1,324 @@
+/**
+ * libh264_amd -- batched MI355X engine behind the libh264 C API (additive).
+ *
+ * The reference library is single threaded and handles one NAL unit per call
+ * (src/h264_reader.c:117-162).  Its C API stays available unchanged in
+ * <h264/h264.h>; this header adds the batched, device-resident form of the
+ * same hot path so that thousands of independent slice NAL units are parsed
+ * by one kernel launch (one slice per wavefront):
+ *
+ *   h264_amd_scan()            <- h264_find_nalu loop   src/h264_bitstream.c:87-184,
+ *                                                        src/h264_reader.c:133-140
+ *   h264_amd_decode_slices()   <- _h264_read_nalu for nal_unit_type 1/5:
+ *                                 slice_header           src/h264_syntax.h:1239-1387
+ *                                 slice_data / MB loop   src/h264_syntax_slice_data.h:701-811
+ *                                 CAVLC residual         src/h264_syntax_slice_data.h:103-419,
+ *                                                        src/h264_slice_data.c:839-1416
+ *   h264_amd_write_slices()    <- h264_write_nalu for slices
+ *                                                        src/h264_writer.c:240-243,
+ *                                                        src/h264_syntax_slice_data.h:813-830
+ *   h264_amd_encode_synth_slices() <- h264_write_grey_i_slice /
+ *                                 h264_write_skipped_p_slice (CAVLC + CABAC)
+ *                                                        src/h264_writer.c:49-309
+ *   h264_amd_cabac_init_states() <- h264_cabac_init_states
+ *                                                        src/h264_cabac_ctx_tables.c:4441-4468
+ *
+ * Plain C ABI: pointers, sizes, POD structs.  Pointers named d_* are DEVICE
+ * pointers (hipMalloc / torch CUDA tensors), everything else is host memory.
+ * All launches are asynchronous on the engine's HIP stream unless stated.
+ * Every function returns 0 or a negative errno; -ENODEV when no usable GPU or
+ * kernel image is present (there is no CPU fallback).
+ */
+#ifndef H264_AMD_H
+#define H264_AMD_H
+
+#include <h264/h264.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+/* ------------------------------------------------------------------------ */
+/* Record formats (shared by the kernels, the host replay and the oracle)    */
+/* ------------------------------------------------------------------------ */
+
+/* One NAL unit found by the scan: payload is buf[start, end). */
+struct h264_amd_nal {
+	uint64_t start;
+	uint64_t end;
+};
+
+/* One slice NAL unit to decode: bytes d_buf[offset, offset+size) hold the NAL
+ * unit WITHOUT start code and WITH emulation-prevention bytes, exactly what
+ * h264_reader_parse_nalu() takes.  `epoch` selects the parameter-set snapshot
+ * that was current at this NAL's position in the stream. */
+struct h264_amd_slice_desc {
+	uint64_t offset;
+	uint32_t size;
+	uint32_t epoch;
+};
+
+/* Macroblock output tiers */
+enum h264_amd_tier {
+	H264_AMD_TIER_NONE = 0, /* per-slice result + checksum only */
+	H264_AMD_TIER_T0 = 1, /* 4 B/MB: first dword of the summary */
+	H264_AMD_TIER_T1 = 2, /* 64 B/MB: struct h264_amd_mb_summary */
+	H264_AMD_TIER_T2 = 3, /* full syntax, h264_amd_t2_stride() B/MB */
+};
+
+/* h264_amd_mb_summary.flags */
+#define H264_AMD_MB_SKIPPED 0x01
+#define H264_AMD_MB_TRANSFORM_8X8 0x02
+#define H264_AMD_MB_FIELD 0x04
+
+/* 64-byte macroblock summary = bytes [0,64) of a T2 record.
+ * Mirrors the fields of the reference's private struct h264_macroblock
+ * (src/h264_macroblock.h:105-167) that are not coefficient arrays. */
+struct h264_amd_mb_summary {
+	uint8_t mb_type; /* enum h264_mb_type */
+	uint8_t cbp; /* CodedBlockPatternLuma | CodedBlockPatternChroma << 4 */
+	uint8_t flags; /* H264_AMD_MB_* */
+	uint8_t raw_mb_type; /* mb_type as coded, low 8 bits */
+	int16_t mb_qp_delta;
+	uint8_t intra_chroma_pred_mode;
+	uint8_t intra16x16_pred_mode;
+	/* intra: 16 (Intra4x4) or 4 (Intra8x8) nibbles, low nibble first,
+	 * nibble = pred_mode + 1 (0 = "predicted", the reference's -1);
+	 * inter with 4 partitions: bytes 0..3 = raw sub_mb_type[0..3] */
+	uint8_t pred[8];
+	/* TotalCoeff per 4x4 block as the reference keeps it for nC
+	 * derivation: [comp*16 + blkIdx], comp 0 Y, 1 Cb, 2 Cr
+	 * (src/h264_slice_data.c:1211-1232,1353-1358) */
+	uint8_t nz_coeff[48];
+};
+
+/* T2 record = 256-byte head + coefficient area of int16:
+ *   [  0, 64)  struct h264_amd_mb_summary
+ *   [ 64, 68)  ref_idx_l0[4]      [ 68, 72)  ref_idx_l1[4]
+ *   [ 72,128)  zero
+ *   [128,192)  mvd_l0[4][4][2] int16     [192,256)  mvd_l1[4][4][2] int16
+ *   [256, ...) coefficient area, int16 units:
+ *      luma  [0,256):  I_16x16: Intra16x16DCLevel[16] then
+ *                      Intra16x16ACLevel[16][15]; otherwise LumaLevel4x4[16][16]
+ *      ChromaArrayType 1/2 (n = 4 or 8 chroma blocks per component):
+ *              ChromaDCLevel[2][n], then ChromaACLevel[2][n][15]
+ *      ChromaArrayType 3: Cb [256,512), Cr [512,768) laid out like luma
+ *      I_PCM: pcm_sample_luma[256] then pcm_sample_chroma[2][MbWidthC*MbHeightC]
+ *              as uint16
+ * Coefficient counts: ChromaArrayType 0: 256, 1: 384, 2: 512, 3: 768. */
+#define H264_AMD_T2_HEAD 256u
+static inline uint32_t h264_amd_t2_coefs(uint32_t chroma_array_type)
+{
+	return chroma_array_type == 0   ? 256u
+	       : chroma_array_type == 1 ? 384u
+	       : chroma_array_type == 2 ? 512u
+					: 768u;
+}
+static inline uint32_t h264_amd_t2_stride(uint32_t chroma_array_type)
+{
+	return H264_AMD_T2_HEAD + 2u * h264_amd_t2_coefs(chroma_array_type);
+}
+
+/* h264_amd_slice_result.flags */
+#define H264_AMD_SR_HEADER_OK 0x0001 /* slice header parsed */
+#define H264_AMD_SR_DATA_PARSED 0x0002 /* slice_data walked (CAVLC) */
+#define H264_AMD_SR_CABAC 0x0004 /* CABAC slice: data kept raw */
+
+/* Engine-specific status values besides negative errno */
+#define H264_AMD_E_UNSUPPORTED (-ENOSYS) /* MBAFF / FMO: out of scope */
+#define H264_AMD_E_MB_OVERFLOW (-EOVERFLOW) /* more MBs than mb_capacity */
+
+/* Per-slice outcome, 64 bytes.  status mirrors what _h264_read_nalu would
+ * have returned for this NAL (0, -EIO, -EINVAL ...). */
+struct h264_amd_slice_result {
+	int32_t status;
+	uint32_t flags; /* H264_AMD_SR_* */
+	uint32_t nal_ref_idc;
+	uint32_t nal_unit_type;
+	int32_t slice_type; /* enum h264_slice_type, -1 if header failed */
+	uint32_t first_mb_in_slice;
+	uint32_t mb_count; /* macroblocks delivered (skipped + coded) */
+	int32_t slice_qp; /* SliceQPLuma */
+	/* ctx->slice.hdr_len: header length in RAW bits, NAL header byte and
+	 * escape bytes included (src/h264_syntax.h:1383) */
+	uint32_t hdr_len_bits;
+	/* ctx->slice.rawdata (src/h264_syntax_slice_data.h:803-806): offset and
+	 * length of the raw slice-data bytes inside the NAL unit, plus the
+	 * <= 7 leftover bits of the header's last byte */
+	uint32_t rawdata_off;
+	uint32_t rawdata_len;
+	uint8_t partial;
+	uint8_t partialbits;
+	uint16_t chroma_array_type;
+	/* RBSP bit position reached (escape bytes not counted); diagnostic */
+	uint32_t end_bit;
+	uint32_t pic_width_in_mbs;
+	/* order-independent checksum over the T2 byte image of every delivered
+	 * macroblock, see h264_amd_checksum_term() */
+	uint64_t checksum;
+};
+
+/* Checksum: sum over macroblock index m and 16-bit word index w (w < 1024) of
+ * the T2 record of term(m * 1024 + w, word).  Zero words contribute nothing,
+ * so the sum can be taken over any partition of the record, in any order. */
+static inline uint64_t h264_amd_checksum_term(uint32_t idx, uint16_t word)
+{
+	uint32_t a = idx * 0x9E3779B1u + 0x85EBCA77u;
+	uint32_t b = (idx ^ 0x5BD1E995u) * 0xC2B2AE3Du + 0x27D4EB2Fu;
+	uint32_t w = word;
+	uint32_t lo = w * a;
+	uint32_t hi = (w * w + w) * b;
+	return ((uint64_t)hi << 32) | lo;
+}
+/* the two 32-bit halves are summed independently (no carry between them) */
+static inline uint64_t h264_amd_checksum_add(uint64_t acc, uint64_t term)
+{
+	uint32_t lo = (uint32_t)acc + (uint32_t)term;
+	uint32_t hi = (uint32_t)(acc >> 32) + (uint32_t)(term >> 32);
+	return ((uint64_t)hi << 32) | lo;
+}
+
+/* ------------------------------------------------------------------------ */
+/* Engine                                                                     */
+/* ------------------------------------------------------------------------ */
+
+struct h264_amd_engine;
+struct h264_amd_params;
+
+/* device: HIP device ordinal.  hip_stream: a hipStream_t to launch on, or NULL
+ * for an engine-owned stream.  -ENODEV if the device or the gfx950 code
+ * object is unusable. */
+H264_API int h264_amd_engine_new(int device,
+				 void *hip_stream,
+				 struct h264_amd_engine **ret);
+H264_API int h264_amd_engine_destroy(struct h264_amd_engine *eng);
+H264_API int h264_amd_engine_sync(struct h264_amd_engine *eng);
+H264_API void *h264_amd_engine_stream(struct h264_amd_engine *eng);
+/* 1 if a GPU usable by this library is present (counts devices only) */
+H264_API int h264_amd_available(void);
+
+/* Plain device memory helpers so that C callers need no HIP headers. */
+H264_API int h264_amd_malloc(struct h264_amd_engine *eng, size_t size, void **d_ptr);
+H264_API int h264_amd_free(struct h264_amd_engine *eng, void *d_ptr);
+H264_API int h264_amd_upload(struct h264_amd_engine *eng,
+			     void *d_dst,
+			     const void *src,
+			     size_t size);
+H264_API int h264_amd_download(struct h264_amd_engine *eng,
+			       void *dst,
+			       const void *d_src,
+			       size_t size);
+H264_API int h264_amd_memset(struct h264_amd_engine *eng,
+			     void *d_dst,
+			     int value,
+			     size_t size);
+
+/* ---- parameter-set snapshots ------------------------------------------- */
+/* A slice binds to the SPS/PPS *versions* active at its stream position
+ * (h264_ctx_set_pps overwrites table entries in place, src/h264_ctx.c:334-355).
+ * The params object records every version and, per epoch, which version each
+ * of the 32 SPS / 256 PPS ids pointed to. */
+H264_API int h264_amd_params_new(struct h264_amd_params **ret);
+H264_API int h264_amd_params_destroy(struct h264_amd_params *p);
+H264_API int h264_amd_params_reset(struct h264_amd_params *p);
+/* return the epoch that is current AFTER the update (>= 0) or -errno */
+H264_API int h264_amd_params_put_sps(struct h264_amd_params *p,
+				     const struct h264_sps *sps);
+H264_API int h264_amd_params_put_pps(struct h264_amd_params *p,
+				     const struct h264_pps *pps);
+H264_API int h264_amd_params_epoch(const struct h264_amd_params *p);
+
+/* ---- Annex-B scan -------------------------------------------------------- */
+/* Finds every NAL unit of d_buf[0,len) with the reference's exact delimiting
+ * rules.  Writes up to `cap` entries, sorted by
+ * start, to d_nals; *count receives the total number found (may exceed cap);
+ * *consumed receives what h264_reader_parse would report in *off.
+ * Synchronous (returns after the table is complete). */
+H264_API int h264_amd_scan(struct h264_amd_engine *eng,
+			   const uint8_t *d_buf,
+			   size_t len,
+			   struct h264_amd_nal *d_nals,
+			   size_t cap,
+			   size_t *count,
+			   size_t *consumed);
+
+/* ---- slice decode -------------------------------------------------------- */
+struct h264_amd_decode_args {
+	const uint8_t *d_buf; /* NAL bytes */
+	const struct h264_amd_slice_desc *d_descs; /* [n] */
+	uint32_t n;
+	uint32_t reader_flags; /* H264_READER_FLAGS_SLICE_DATA or 0 */
+	uint32_t tier; /* enum h264_amd_tier */
+	uint32_t mb_capacity; /* macroblock records per slice */
+	struct h264_amd_slice_result *d_results; /* [n] */
+	struct h264_slice_header *d_headers; /* [n] byte images, or NULL */
+	uint8_t *d_mb_out; /* n * mb_capacity * mb_stride bytes, or NULL */
+	uint32_t mb_stride; /* bytes per MB record for the tier */
+	uint32_t reserved;
+};
+H264_API int h264_amd_decode_slices(struct h264_amd_engine *eng,
+				    const struct h264_amd_params *params,
+				    const struct h264_amd_decode_args *args);
+
+/* ---- slice write-back (round trip) -------------------------------------- */
+struct h264_amd_write_args {
+	const uint8_t *d_src; /* original NAL bytes (raw slice data source) */
+	const struct h264_amd_slice_desc *d_descs; /* [n] */
+	const struct h264_amd_slice_result *d_results; /* [n] from decode */
+	const struct h264_slice_header *d_headers; /* [n] from decode */
+	uint32_t n;
+	uint32_t reserved;
+	uint8_t *d_out; /* output NAL bytes */
+	const uint64_t *d_out_offsets; /* [n] where each NAL goes in d_out */
+	uint32_t *d_out_sizes; /* [n] bytes written, or negative errno cast */
+	uint32_t out_capacity; /* per-NAL capacity in bytes */
+	uint32_t reserved2;
+};
+H264_API int h264_amd_write_slices(struct h264_amd_engine *eng,
+				   const struct h264_amd_params *params,
+				   const struct h264_amd_write_args *args);
+
+/* ---- synthetic slices (CAVLC and CABAC) --------------------------------- */
+enum h264_amd_synth_kind {
+	H264_AMD_SYNTH_GREY_I = 0, /* h264_write_grey_i_slice */
+	H264_AMD_SYNTH_SKIP_P = 1, /* h264_write_skipped_p_slice */
+};
+struct h264_amd_synth_desc {
+	uint32_t kind; /* enum h264_amd_synth_kind */
+	uint32_t epoch;
+	uint32_t mb_count;
+	uint32_t nal_ref_idc;
+	uint32_t nal_unit_type;
+	uint32_t reserved;
+};
+struct h264_amd_synth_args {
+	const struct h264_amd_synth_desc *d_descs; /* [n] */
+	const struct h264_slice_header *d_headers; /* [n] */
+	uint32_t n;
+	uint32_t out_capacity; /* per-NAL capacity in bytes */
+	uint8_t *d_out;
+	const uint64_t *d_out_offsets; /* [n] */
+	int32_t *d_out_sizes; /* [n] bytes written or negative errno */
+};
+H264_API int h264_amd_encode_synth_slices(struct h264_amd_engine *eng,
+					  const struct h264_amd_params *params,
+					  const struct h264_amd_synth_args *args);
+
+/* CABAC context initialisation for n (slice_type, cabac_init_idc, SliceQPLuma)
+ * triples: d_states[n][1024][2] = {pStateIdx, valMPS}. */
+H264_API int h264_amd_cabac_init_states(struct h264_amd_engine *eng,
+					const int32_t *d_triples, /* [n][3] */
+					uint32_t n,
+					uint8_t *d_states);
+
+/* Kernel timing: duration in ms of the most recent launch of the named
+ * kernel family ("scan", "decode", "write", "synth"), measured with HIP
+ * events on the engine stream.  Synchronises. */
+H264_API int h264_amd_last_kernel_ms(struct h264_amd_engine *eng,
+				     const char *family,
+				     float *ms);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* H264_AMD_H */

@@ -1,0 +1,319 @@
+/**
+ * oracle/ -- CPU restatement of the reference algorithm.  TEST INFRASTRUCTURE.
+ *
+ * Plain-C, bit-serial restatement of Parrot-Developers/libh264's reader,
+ * CAVLC slice_data parser, writer and CABAC encoder, function by function,
+ * each citing the reference file:line it follows.  It exists to CHECK the HIP
+ * path; only tests/, __graft_entry__.smoke() and bench.py's cpu_baseline leg
+ * may load it.  The product (libh264_amd/) never links, imports or executes
+ * anything in this directory.
+ *
+ * PINNING STATUS -- "parity unpinned" except where stated:
+ *   The reference cannot be built in this image without writing a stand-in
+ *   for <ulog.h> (libulog is absent), and it ships no golden vectors.  What
+ *   pins this restatement to the real reference is therefore limited to
+ *     (a) oracle/_ref: the reference's OWN public header
+ *         include/h264/h264_bitstream.h compiled as it lies (its static-inline
+ *         bit reader needs no missing dependency) -- pins fetch/EPB/read_bits;
+ *     (b) the constant tables, compared entry by entry with the reference's
+ *         source text when /root/reference is present
+ *         (tests/test_spec_tables.py);
+ *     (c) known answers the survey recorded from a real reference run
+ *         (BASELINE.md section 2): struct sizes,
+ *         SPS/PPS byte strings, synthetic-slice sizes -- tests/golden/.
+ *   Everything else is restated from reading the source and is unpinned.
+ *
+ * All oracle symbols carry the orc_ prefix and operate on the public struct
+ * types of include/h264/ so that records are byte-comparable with the product.
+ */
+#ifndef ORC_H
+#define ORC_H
+
+#include <h264/h264.h>
+#include <h264_amd.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+/* ---- private macroblock state (ref src/h264_macroblock.h:36-167) --------- */
+
+enum orc_sub_mb_type {
+	ORC_SUB_P_8x8,
+	ORC_SUB_P_8x4,
+	ORC_SUB_P_4x8,
+	ORC_SUB_P_4x4,
+	ORC_SUB_B_Direct_8x8,
+	ORC_SUB_B_8x8,
+	ORC_SUB_B_8x4,
+	ORC_SUB_B_4x8,
+	ORC_SUB_B_4x4,
+};
+
+enum orc_pred_mode {
+	ORC_PRED_Intra_4x4,
+	ORC_PRED_Intra_8x8,
+	ORC_PRED_Intra_16x16,
+	ORC_PRED_L0,
+	ORC_PRED_L1,
+	ORC_PRED_Bi,
+	ORC_PRED_Direct,
+};
+
+/* residual block classes (ref enum Level, src/h264_macroblock.h:62-74) */
+enum orc_level_kind {
+	ORC_LVL_I16DC,
+	ORC_LVL_I16AC,
+	ORC_LVL_CB_I16DC,
+	ORC_LVL_CB_I16AC,
+	ORC_LVL_CR_I16DC,
+	ORC_LVL_CR_I16AC,
+	ORC_LVL_LUMA4x4,
+	ORC_LVL_CB4x4,
+	ORC_LVL_CR4x4,
+	ORC_LVL_CHROMA_DC,
+	ORC_LVL_CHROMA_AC,
+};
+
+#define ORC_MB_ADDR_INVALID 0xffffffffu
+
+/* per-MB neighbour context kept for the whole slice
+ * (ref struct h264_macroblock_info, src/h264_macroblock.h:94-101) */
+struct orc_mb_info {
+	uint8_t mb_type; /* reference stores 4 bits */
+	uint8_t intra_chroma_pred_mode;
+	uint8_t available;
+	uint8_t skipped;
+	uint8_t field_flag;
+	uint8_t nz_coeff[48];
+};
+
+/* current macroblock (ref struct h264_macroblock, :105-167) */
+struct orc_mb {
+	uint32_t mbAddr;
+	int mb_field_decoding_flag;
+	uint32_t mbAddrA, mbAddrB;
+	const struct orc_mb_info *infoA, *infoB;
+
+	uint32_t mb_type;
+	uint32_t raw_mb_type;
+	uint32_t NumMbPart;
+	uint32_t MbPartPredMode[4];
+	uint32_t raw_sub_mb_type[4];
+	uint32_t sub_mb_type[4];
+	uint32_t NumSubMbPart[4];
+	uint32_t SubMbPredMode[4];
+	int transform_size_8x8_flag;
+	int32_t mb_qp_delta;
+
+	uint16_t pcm_sample_luma[256];
+	uint16_t pcm_sample_chroma[2][256];
+
+	int8_t intra4x4_pred_mode[16];
+	int8_t intra8x8_pred_mode[4];
+	uint8_t intra_chroma_pred_mode;
+	uint8_t Intra16x16PredMode;
+
+	uint8_t max_ref_idx_0, max_ref_idx_1;
+	uint8_t ref_idx_l0[4], ref_idx_l1[4];
+	int16_t mvd_l0[4][4][2], mvd_l1[4][4][2];
+
+	uint8_t coded_block_pattern;
+	uint8_t CodedBlockPatternLuma;
+	uint8_t CodedBlockPatternChroma;
+
+	/* [0]=Y, [1]=Cb, [2]=Cr for the 4:4:4 triple; chroma DC/AC for 4:2:x */
+	int16_t I16DC[3][16];
+	int16_t I16AC[3][16][15];
+	int16_t Lvl4x4[3][16][16];
+	int16_t Lvl8x8[3][4][64];
+	int16_t ChromaDC[2][16];
+	int16_t ChromaAC[2][16][15];
+};
+
+struct orc_sei_entry {
+	struct h264_sei sei;
+};
+
+/* parsing context (ref struct h264_ctx, src/h264_priv.h:67-140) */
+struct orc_ctx {
+	struct {
+		uint32_t type;
+		struct h264_nalu_header hdr;
+		int unknown;
+		int is_first_vcl;
+		int is_prev_vcl;
+		int is_prev_filler;
+	} nalu;
+	struct h264_aud aud;
+	struct h264_sps *sps;
+	struct h264_pps *pps;
+	struct h264_sps *sps_table[32];
+	struct h264_pps *pps_table[256];
+	struct h264_sei *sei_table;
+	uint32_t sei_count;
+	size_t filler_len;
+	struct {
+		int type; /* enum h264_slice_type */
+		struct h264_slice_header hdr;
+		size_t hdr_len;
+		struct h264_slice_header saved_hdr;
+		struct {
+			uint8_t partial;
+			uint8_t partialbits;
+			const uint8_t *buf;
+			size_t len;
+		} rawdata;
+		struct {
+			struct orc_mb_info *info;
+			size_t len, maxlen;
+		} mb_table;
+		struct h264_nalu_header prev_slice_nalu_hdr;
+		struct h264_slice_header prev_slice_hdr;
+	} slice;
+	struct orc_mb _mb;
+	struct orc_mb *mb;
+	struct h264_sps_derived sps_derived;
+	struct {
+		uint32_t SliceGroupChangeRate;
+		int MbaffFrameFlag;
+		uint32_t PicHeightInMbs;
+		uint32_t PicSizeInMbs;
+		uint32_t MaxPicNum, CurrPicNum;
+		int32_t SliceQPLuma, QSLuma;
+		uint32_t FilterOffsetA, FilterOffsetB;
+		uint32_t MapUnitsInSliceGroup0;
+	} derived;
+	/* bits of RBSP consumed inside the current NAL (diagnostic, for
+	 * h264_amd_slice_result.end_bit) */
+	const struct h264_bitstream *cur_bs;
+};
+
+/* Callbacks: same table as the public API but ctx is the oracle's. */
+struct orc_cbs {
+	void (*au_end)(struct orc_ctx *, void *);
+	void (*nalu_begin)(struct orc_ctx *, uint32_t, const uint8_t *, size_t,
+			   const struct h264_nalu_header *, void *);
+	void (*nalu_end)(struct orc_ctx *, uint32_t, const uint8_t *, size_t,
+			 const struct h264_nalu_header *, void *);
+	void (*slice)(struct orc_ctx *, const uint8_t *, size_t,
+		      const struct h264_slice_header *, void *);
+	void (*slice_data_begin)(struct orc_ctx *,
+				 const struct h264_slice_header *, void *);
+	void (*slice_data_end)(struct orc_ctx *,
+			       const struct h264_slice_header *, uint32_t,
+			       void *);
+	void (*slice_data_mb)(struct orc_ctx *,
+			      const struct h264_slice_header *, uint32_t,
+			      uint32_t, void *);
+	void (*sps)(struct orc_ctx *, const uint8_t *, size_t,
+		    const struct h264_sps *, void *);
+	void (*pps)(struct orc_ctx *, const uint8_t *, size_t,
+		    const struct h264_pps *, void *);
+	void (*aud)(struct orc_ctx *, const uint8_t *, size_t,
+		    const struct h264_aud *, void *);
+	void (*sei)(struct orc_ctx *, uint32_t, const uint8_t *, size_t, void *);
+	void (*sei_typed)(struct orc_ctx *, uint32_t type, const uint8_t *,
+			  size_t, const struct h264_sei *, void *);
+};
+
+struct orc_reader {
+	struct orc_cbs cbs;
+	void *userdata;
+	int stop;
+	struct orc_ctx *ctx;
+	uint32_t flags;
+};
+
+/* ---- bit level (orc_bits.c; ref include/h264/h264_bitstream.h,
+ *      src/h264_bitstream.c) -------------------------------------------- */
+int orc_find_nalu(const uint8_t *buf, size_t len, size_t *start, size_t *end);
+int orc_bs_fetch(struct h264_bitstream *bs);
+int orc_bs_read_bits(struct h264_bitstream *bs, uint32_t *v, uint32_t n);
+int orc_bs_read_bits_i(struct h264_bitstream *bs, int32_t *v, uint32_t n);
+int orc_bs_read_ue(struct h264_bitstream *bs, uint32_t *v);
+int orc_bs_read_se(struct h264_bitstream *bs, int32_t *v);
+int orc_bs_read_te(struct h264_bitstream *bs, uint32_t *v, uint32_t m);
+int orc_bs_read_ff(struct h264_bitstream *bs, uint32_t *v);
+int orc_bs_more_rbsp_data(const struct h264_bitstream *bs);
+int orc_bs_next_bits(const struct h264_bitstream *bs, uint32_t *v, uint32_t n);
+int orc_bs_read_trailing(struct h264_bitstream *bs);
+int orc_bs_write_bits(struct h264_bitstream *bs, uint64_t v, uint32_t n);
+int orc_bs_write_ue(struct h264_bitstream *bs, uint32_t v);
+int orc_bs_write_se(struct h264_bitstream *bs, int32_t v);
+int orc_bs_write_te(struct h264_bitstream *bs, uint32_t v, uint32_t m);
+int orc_bs_write_ff(struct h264_bitstream *bs, uint32_t v);
+int orc_bs_write_trailing(struct h264_bitstream *bs);
+int orc_bs_write_raw_bytes(struct h264_bitstream *bs, const uint8_t *buf,
+			   size_t len);
+/* number of RBSP bits consumed so far by a reader cursor (ours, diagnostic) */
+uint64_t orc_bs_rbsp_bits_consumed(const struct h264_bitstream *bs);
+
+/* ---- context (orc_ctx.c; ref src/h264_ctx.c, src/h264.c) -------------- */
+int orc_ctx_new(struct orc_ctx **ret);
+int orc_ctx_destroy(struct orc_ctx *ctx);
+int orc_ctx_clear(struct orc_ctx *ctx);
+int orc_ctx_clear_nalu(struct orc_ctx *ctx);
+int orc_ctx_clear_slice(struct orc_ctx *ctx);
+int orc_ctx_clear_sei_table(struct orc_ctx *ctx);
+int orc_ctx_set_nalu_header(struct orc_ctx *ctx,
+			    const struct h264_nalu_header *nh);
+int orc_ctx_set_sps(struct orc_ctx *ctx, const struct h264_sps *sps);
+int orc_ctx_set_pps(struct orc_ctx *ctx, const struct h264_pps *pps);
+int orc_ctx_set_active_sps(struct orc_ctx *ctx, uint32_t id);
+int orc_ctx_set_active_pps(struct orc_ctx *ctx, uint32_t id);
+int orc_ctx_set_slice_header(struct orc_ctx *ctx,
+			     const struct h264_slice_header *sh);
+int orc_ctx_add_sei_internal(struct orc_ctx *ctx, struct h264_sei **ret);
+int orc_ctx_add_sei(struct orc_ctx *ctx, const struct h264_sei *sei);
+int orc_get_sps_derived(const struct h264_sps *sps,
+			struct h264_sps_derived *d);
+int orc_get_info_from_ps(const struct h264_sps *sps,
+			 const struct h264_sps_derived *d,
+			 struct h264_info *info);
+int orc_sei_update_internal_buf(struct h264_sei *sei);
+uint32_t orc_intlog2(uint32_t x);
+
+/* ---- syntax (orc_syntax.c; ref src/h264_syntax.h) --------------------- */
+int orc_read_nalu_header(struct h264_bitstream *bs, struct h264_nalu_header *nh);
+int orc_read_nalu(struct h264_bitstream *bs, struct orc_reader *rd);
+int orc_write_nalu(struct h264_bitstream *bs, struct orc_ctx *ctx);
+int orc_write_one_sei(struct h264_bitstream *bs, struct orc_ctx *ctx,
+		      const struct h264_sei *sei);
+int orc_parse_sps(const uint8_t *buf, size_t len, struct h264_sps *sps);
+int orc_parse_pps(const uint8_t *buf, size_t len, const struct h264_sps *sps,
+		  struct h264_pps *pps);
+
+/* ---- CAVLC slice data (orc_cavlc.c; ref src/h264_syntax_slice_data.h,
+ *      src/h264_slice_data.c, src/h264_macroblock.c) ------------------ */
+int orc_read_slice_data(struct h264_bitstream *bs, struct orc_reader *rd);
+int orc_new_macroblock(struct orc_ctx *ctx, uint32_t mbAddr, int skipped,
+		       int field_flag);
+void orc_clear_macroblock_table(struct orc_ctx *ctx);
+/* serialise ctx->mb into the engine's T2 macroblock record */
+void orc_mb_to_record(const struct orc_ctx *ctx, uint8_t *rec, uint32_t stride);
+
+/* ---- CABAC encoder + synthetic slices (orc_cabac.c; ref src/h264_bac.c,
+ *      src/h264_cabac.c, src/h264_cabac_ctx_tables.c, src/h264_writer.c) */
+void orc_cabac_init_states(int slice_type, uint32_t cabac_init_idc,
+			   int32_t SliceQPLuma, uint8_t states[1024][2]);
+int orc_write_grey_i_slice(struct h264_bitstream *bs, struct orc_ctx *ctx,
+			   uint32_t mb_count);
+int orc_write_skipped_p_slice(struct h264_bitstream *bs, struct orc_ctx *ctx,
+			      uint32_t mb_count);
+int orc_rewrite_slice_header(struct h264_bitstream *bs, struct orc_ctx *ctx,
+			     const struct h264_slice_header *sh);
+
+/* ---- reader object + recorder (orc_api.c; ref src/h264_reader.c) ------ */
+int orc_reader_new(const struct orc_cbs *cbs, void *userdata,
+		   struct orc_reader **ret);
+int orc_reader_destroy(struct orc_reader *rd);
+int orc_reader_parse(struct orc_reader *rd, uint32_t flags, const uint8_t *buf,
+		     size_t len, size_t *off);
+int orc_reader_parse_nalu(struct orc_reader *rd, uint32_t flags,
+			  const uint8_t *buf, size_t len);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* ORC_H */
