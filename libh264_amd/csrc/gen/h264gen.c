@@ -1,0 +1,1162 @@
+/**
+ * h264gen.c -- seeded synthetic H.264 stream generator (see h264gen.h).
+ *
+ * An ENCODER for the syntax the engine parses: SPS/PPS (7.3.2.1, 7.3.2.2),
+ * slice header (7.3.3), slice_data / macroblock_layer / mb_pred / sub_mb_pred
+ * (7.3.4, 7.3.5) and CAVLC residual blocks (9.2), driven by a xorshift
+ * generator.  Code tables come from the standard's bit strings in
+ * ../common/h264_cavlc_tables.inc, inverted here for encoding.
+ */
+#define _GNU_SOURCE
+#include "h264gen.h"
+
+#include <errno.h>
+#include <pthread.h>
+#include <stdlib.h>
+#include <string.h>
+
+/* ---- T2 record layout constants (mirror of <h264_amd.h>) --------------- */
+#define T2_HEAD 256u
+#define MBF_SKIPPED 0x01
+#define MBF_T8X8 0x02
+
+enum { MB_UNKNOWN, MB_I_NxN, MB_I_16x16, MB_I_PCM, MB_SI, MB_P_16x16,
+       MB_P_16x8, MB_P_8x16, MB_P_8x8, MB_P_8x8ref0, MB_P_SKIP,
+       MB_B_Direct_16x16, MB_B_16x16, MB_B_16x8, MB_B_8x16, MB_B_8x8,
+       MB_B_SKIP };
+
+enum { PM_L0 = 1, PM_L1 = 2, PM_BI = 3, PM_DIRECT = 4 };
+
+/* ---- random numbers ----------------------------------------------------- */
+struct rng {
+	uint64_t s;
+};
+
+static uint64_t rng_next(struct rng *r)
+{
+	uint64_t x = r->s;
+	x ^= x >> 12;
+	x ^= x << 25;
+	x ^= x >> 27;
+	r->s = x;
+	return x * 0x2545F4914F6CDD1Dull;
+}
+
+static uint32_t rng_below(struct rng *r, uint32_t n)
+{
+	return n ? (uint32_t)((rng_next(r) >> 32) % n) : 0;
+}
+
+static int rng_pm(struct rng *r, uint32_t per_mille)
+{
+	return rng_below(r, 1000) < per_mille;
+}
+
+/* ---- emulation-preventing bit writer ------------------------------------ */
+struct bw {
+	uint8_t *p;
+	size_t cap, off;
+	uint32_t acc;
+	int nbits;
+	int zeros;
+	int overflow;
+};
+
+static void bw_init(struct bw *w, uint8_t *p, size_t cap)
+{
+	memset(w, 0, sizeof(*w));
+	w->p = p;
+	w->cap = cap;
+}
+
+static void bw_byte(struct bw *w, uint8_t b)
+{
+	if (w->zeros >= 2 && b <= 3) {
+		if (w->off < w->cap)
+			w->p[w->off] = 3;
+		else
+			w->overflow = 1;
+		w->off++;
+		w->zeros = 0;
+	}
+	if (w->off < w->cap)
+		w->p[w->off] = b;
+	else
+		w->overflow = 1;
+	w->off++;
+	w->zeros = b == 0 ? w->zeros + 1 : 0;
+}
+
+static void bw_u(struct bw *w, uint32_t v, int n)
+{
+	while (n > 0) {
+		int k = 8 - w->nbits;
+		if (k > n)
+			k = n;
+		w->acc = (w->acc << k) | ((v >> (n - k)) & ((1u << k) - 1));
+		w->nbits += k;
+		n -= k;
+		if (w->nbits == 8) {
+			bw_byte(w, (uint8_t)w->acc);
+			w->acc = 0;
+			w->nbits = 0;
+		}
+	}
+}
+
+static void bw_ue(struct bw *w, uint32_t v)
+{
+	uint32_t x = v + 1;
+	int n = 0;
+	uint32_t t;
+	for (t = x; t; t >>= 1)
+		n++;
+	if (n > 1)
+		bw_u(w, 0, n - 1);
+	bw_u(w, x, n);
+}
+
+static void bw_se(struct bw *w, int32_t v)
+{
+	bw_ue(w, v > 0 ? (uint32_t)(2 * v - 1) : (uint32_t)(-2 * v));
+}
+
+static void bw_te(struct bw *w, uint32_t v, uint32_t range)
+{
+	if (range == 1)
+		bw_u(w, !v, 1);
+	else
+		bw_ue(w, v);
+}
+
+static void bw_trailing(struct bw *w)
+{
+	bw_u(w, 1, 1);
+	while (w->nbits != 0)
+		bw_u(w, 0, 1);
+}
+
+/* ---- code tables, inverted for encoding --------------------------------- */
+struct code {
+	uint16_t bits;
+	uint8_t len;
+};
+
+static struct code s_ct[6][4][17];
+static struct code s_tz[16][16], s_tzc420[4][4], s_tzc422[8][8], s_rb[8][15];
+static uint8_t s_cbp_code[2][2][48]; /* [class][intra/inter][cbp] -> codeNum */
+static pthread_once_t s_once = PTHREAD_ONCE_INIT;
+
+static struct code mk(const char *s)
+{
+	struct code c = {0, 0};
+	for (; *s; s++) {
+		if (*s == '0' || *s == '1') {
+			c.bits = (uint16_t)((c.bits << 1) | (*s - '0'));
+			c.len++;
+		}
+	}
+	return c;
+}
+
+static void tables_init(void)
+{
+#define H264_CT(col, bits, t1, tc) s_ct[col][t1][tc] = mk(bits);
+#define H264_TZ(i, bits, v) s_tz[i][v] = mk(bits);
+#define H264_TZ_C420(i, bits, v) s_tzc420[i][v] = mk(bits);
+#define H264_TZ_C422(i, bits, v) s_tzc422[i][v] = mk(bits);
+#define H264_RB(i, bits, v) s_rb[i][v] = mk(bits);
+#define H264_CBP(cls, code, intra, inter)                                      \
+	s_cbp_code[cls][0][intra] = code;                                      \
+	s_cbp_code[cls][1][inter] = code;
+#include "../common/h264_cavlc_tables.inc"
+}
+
+static void put_code(struct bw *w, struct code c)
+{
+	bw_u(w, c.bits, c.len);
+}
+
+/* ---- parameter sets ------------------------------------------------------ */
+static int is_high(uint32_t p)
+{
+	return p == 100 || p == 110 || p == 122 || p == 244 || p == 44;
+}
+
+static uint32_t chroma_array_type(const struct h264gen_cfg *c)
+{
+	return is_high(c->profile_idc) ? c->chroma_format_idc : 1;
+}
+
+static int finish(struct bw *w)
+{
+	if (w->overflow)
+		return -ENOBUFS;
+	return (int)w->off;
+}
+
+int h264gen_sps(const struct h264gen_cfg *c, uint8_t *out, size_t cap)
+{
+	struct bw w;
+	bw_init(&w, out, cap);
+	bw_u(&w, 0x67, 8);
+	bw_u(&w, c->profile_idc, 8);
+	bw_u(&w, 0, 8); /* constraint flags + reserved */
+	bw_u(&w, c->level_idc, 8);
+	bw_ue(&w, c->sps_id);
+	if (is_high(c->profile_idc)) {
+		bw_ue(&w, c->chroma_format_idc);
+		if (c->chroma_format_idc == 3)
+			bw_u(&w, 0, 1); /* separate_colour_plane_flag */
+		bw_ue(&w, c->bit_depth_luma_minus8);
+		bw_ue(&w, c->bit_depth_chroma_minus8);
+		bw_u(&w, 0, 1); /* qpprime_y_zero_transform_bypass_flag */
+		bw_u(&w, 0, 1); /* seq_scaling_matrix_present_flag */
+	}
+	bw_ue(&w, c->log2_max_frame_num_minus4);
+	bw_ue(&w, c->pic_order_cnt_type);
+	if (c->pic_order_cnt_type == 0)
+		bw_ue(&w, c->log2_max_poc_lsb_minus4);
+	bw_ue(&w, c->max_num_ref_frames);
+	bw_u(&w, 0, 1); /* gaps_in_frame_num_value_allowed_flag */
+	bw_ue(&w, c->width_mbs - 1);
+	bw_ue(&w, c->height_mbs - 1);
+	bw_u(&w, 1, 1); /* frame_mbs_only_flag */
+	bw_u(&w, c->direct_8x8_inference_flag, 1);
+	if (c->crop_bottom) {
+		bw_u(&w, 1, 1);
+		bw_ue(&w, 0);
+		bw_ue(&w, 0);
+		bw_ue(&w, 0);
+		bw_ue(&w, c->crop_bottom);
+	} else {
+		bw_u(&w, 0, 1);
+	}
+	if (c->vui) {
+		bw_u(&w, 1, 1);
+		bw_u(&w, 1, 1); /* aspect_ratio_info_present_flag */
+		bw_u(&w, 1, 8); /* 1:1 */
+		bw_u(&w, 0, 1); /* overscan */
+		bw_u(&w, 1, 1); /* video_signal_type_present_flag */
+		bw_u(&w, 5, 3);
+		bw_u(&w, 1, 1); /* full range */
+		bw_u(&w, 1, 1); /* colour description */
+		bw_u(&w, 1, 8);
+		bw_u(&w, 1, 8);
+		bw_u(&w, 1, 8);
+		bw_u(&w, 0, 1); /* chroma loc */
+		bw_u(&w, 1, 1); /* timing_info_present_flag */
+		bw_u(&w, 1001, 32);
+		bw_u(&w, 60000, 32);
+		bw_u(&w, 1, 1);
+		bw_u(&w, 0, 1); /* nal hrd */
+		bw_u(&w, 0, 1); /* vcl hrd */
+		bw_u(&w, 0, 1); /* pic_struct_present_flag */
+		bw_u(&w, 1, 1); /* bitstream_restriction_flag */
+		bw_u(&w, 1, 1);
+		bw_ue(&w, 0);
+		bw_ue(&w, 0);
+		bw_ue(&w, 10);
+		bw_ue(&w, 10);
+		bw_ue(&w, 0);
+		bw_ue(&w, c->max_num_ref_frames);
+	} else {
+		bw_u(&w, 0, 1);
+	}
+	bw_trailing(&w);
+	return finish(&w);
+}
+
+int h264gen_pps(const struct h264gen_cfg *c, uint8_t *out, size_t cap)
+{
+	struct bw w;
+	bw_init(&w, out, cap);
+	bw_u(&w, 0x68, 8);
+	bw_ue(&w, c->pps_id);
+	bw_ue(&w, c->sps_id);
+	bw_u(&w, c->entropy_coding_mode_flag, 1);
+	bw_u(&w, c->bottom_field_pic_order_in_frame_present_flag, 1);
+	bw_ue(&w, 0); /* num_slice_groups_minus1 */
+	bw_ue(&w, c->num_ref_idx_l0_default_minus1);
+	bw_ue(&w, c->num_ref_idx_l1_default_minus1);
+	bw_u(&w, c->weighted_pred_flag, 1);
+	bw_u(&w, c->weighted_bipred_idc, 2);
+	bw_se(&w, c->pic_init_qp_minus26);
+	bw_se(&w, 0);
+	bw_se(&w, 0);
+	bw_u(&w, c->deblocking_filter_control_present_flag, 1);
+	bw_u(&w, c->constrained_intra_pred_flag, 1);
+	bw_u(&w, c->redundant_pic_cnt_present_flag, 1);
+	if (c->transform_8x8_mode_flag) {
+		bw_u(&w, 1, 1);
+		bw_u(&w, 0, 1); /* pic_scaling_matrix_present_flag */
+		bw_se(&w, 0); /* second_chroma_qp_index_offset */
+	}
+	bw_trailing(&w);
+	return finish(&w);
+}
+
+int h264gen_aud(uint32_t primary_pic_type, uint8_t *out, size_t cap)
+{
+	struct bw w;
+	bw_init(&w, out, cap);
+	bw_u(&w, 0x09, 8);
+	bw_u(&w, primary_pic_type, 3);
+	bw_trailing(&w);
+	return finish(&w);
+}
+
+int h264gen_filler(uint32_t n_ff, uint8_t *out, size_t cap)
+{
+	struct bw w;
+	uint32_t i;
+	bw_init(&w, out, cap);
+	bw_u(&w, 0x0c, 8);
+	for (i = 0; i < n_ff; i++)
+		bw_u(&w, 0xff, 8);
+	bw_trailing(&w);
+	return finish(&w);
+}
+
+int h264gen_sei_user_data(uint32_t n, uint64_t seed, uint8_t *out, size_t cap)
+{
+	struct bw w;
+	struct rng r = {seed | 1};
+	uint32_t size = 16 + n, i, s;
+	bw_init(&w, out, cap);
+	bw_u(&w, 0x06, 8);
+	bw_u(&w, 5, 8); /* user_data_unregistered */
+	for (s = size; s >= 255; s -= 255)
+		bw_u(&w, 0xff, 8);
+	bw_u(&w, s, 8);
+	for (i = 0; i < size; i++)
+		bw_u(&w, rng_below(&r, 8) == 0 ? 0 : rng_below(&r, 256), 8);
+	bw_trailing(&w);
+	return finish(&w);
+}
+
+/* ---- slice state --------------------------------------------------------- */
+struct gen {
+	const struct h264gen_cfg *c;
+	const struct h264gen_slice *s;
+	struct bw w;
+	struct rng r;
+	uint32_t cat, W;
+	uint32_t st; /* slice type mod 5 */
+	uint32_t nref0, nref1; /* num_ref_idx_lX_active_minus1 */
+	uint8_t *nz; /* [num_mbs][48] */
+	uint8_t *t2;
+	uint32_t t2_stride;
+};
+
+static uint8_t *rec_of(struct gen *g, uint32_t i)
+{
+	return g->t2 ? g->t2 + (size_t)i * g->t2_stride : NULL;
+}
+
+static int16_t *coef_of(uint8_t *rec)
+{
+	return (int16_t *)(rec + T2_HEAD);
+}
+
+/* availability + TotalCoeff of the neighbouring 4x4 block (6.4.11.4) */
+static uint32_t neighbour_nc(struct gen *g, uint32_t i, uint32_t comp,
+			     uint32_t blk, int chroma)
+{
+	uint32_t addr = g->s->first_mb + i;
+	int availA, availB;
+	uint32_t nA = 0, nB = 0, x, y, bw4, bh4;
+	const uint8_t *cur = g->nz + (size_t)i * 48 + comp * 16;
+	static const uint8_t lx[16] = {0, 1, 0, 1, 2, 3, 2, 3,
+				       0, 1, 0, 1, 2, 3, 2, 3};
+	static const uint8_t ly[16] = {0, 0, 1, 1, 0, 0, 1, 1,
+				       2, 2, 3, 3, 2, 2, 3, 3};
+	static const uint8_t lidx[4][4] = {/* [y][x] */
+					   {0, 1, 4, 5},
+					   {2, 3, 6, 7},
+					   {8, 9, 12, 13},
+					   {10, 11, 14, 15}};
+	if (chroma) {
+		x = blk & 1;
+		y = blk >> 1;
+		bw4 = 2;
+		bh4 = g->cat == 1 ? 2 : 4;
+	} else {
+		x = lx[blk];
+		y = ly[blk];
+		bw4 = 4;
+		bh4 = 4;
+	}
+	/* left */
+	if (x > 0) {
+		availA = 1;
+		nA = chroma ? cur[2 * y + x - 1] : cur[lidx[y][x - 1]];
+	} else {
+		availA = (addr % g->W != 0) && i >= 1;
+		if (availA) {
+			const uint8_t *l = cur - 48;
+			nA = chroma ? l[2 * y + bw4 - 1] : l[lidx[y][bw4 - 1]];
+		}
+	}
+	/* above */
+	if (y > 0) {
+		availB = 1;
+		nB = chroma ? cur[2 * (y - 1) + x] : cur[lidx[y - 1][x]];
+	} else {
+		availB = i >= g->W;
+		if (availB) {
+			const uint8_t *t = cur - (size_t)48 * g->W;
+			nB = chroma ? t[2 * (bh4 - 1) + x] : t[lidx[bh4 - 1][x]];
+		}
+	}
+	if (availA && availB)
+		return (nA + nB + 1) >> 1;
+	if (availA)
+		return nA;
+	if (availB)
+		return nB;
+	return 0;
+}
+
+/* one level with the running suffixLength (inverse of 9.2.2.1) */
+static void put_level(struct bw *w, int32_t level, uint32_t *sl, int first_adj)
+{
+	uint32_t a = level < 0 ? (uint32_t)-level : (uint32_t)level;
+	uint32_t code = level > 0 ? 2 * a - 2 : 2 * a - 1;
+	uint32_t s = *sl, prefix, esc;
+	if (first_adj)
+		code -= 2;
+	if (s == 0 && code < 14) {
+		bw_u(w, 1, (int)code + 1);
+	} else if (s == 0 && code < 30) {
+		bw_u(w, 1, 15);
+		bw_u(w, code - 14, 4);
+	} else if (s > 0 && (code >> s) < 15) {
+		bw_u(w, 1, (int)(code >> s) + 1);
+		bw_u(w, code & ((1u << s) - 1), (int)s);
+	} else {
+		esc = code - (s == 0 ? 30 : (15u << s));
+		if (esc < 4096) {
+			prefix = 15;
+		} else {
+			/* level_prefix p >= 16 covers
+			 * [2^(p-3) - 4096, 2^(p-2) - 4096) */
+			prefix = 16;
+			while (esc >= (1u << (prefix - 2)) - 4096)
+				prefix++;
+			esc -= (1u << (prefix - 3)) - 4096;
+		}
+		bw_u(w, 0, (int)prefix);
+		bw_u(w, 1, 1);
+		bw_u(w, esc, (int)prefix - 3);
+	}
+	if (s == 0)
+		s = 1;
+	if (a > (3u << (s - 1)) && s < 6)
+		s++;
+	*sl = s;
+}
+
+/* Encode one residual block with random content.
+ * coefs: where the expected coefficients go (max entries), may be NULL.
+ * returns TotalCoeff */
+static uint32_t put_block(struct gen *g, uint32_t maxnum, uint32_t col,
+			  int16_t *coefs)
+{
+	struct bw *w = &g->w;
+	uint32_t tc, t1, i, sl, tz, zleft;
+	int32_t lv[16];
+	uint32_t run[16];
+	uint32_t d = g->s->density;
+
+	/* TotalCoeff: mostly small, occasionally full */
+	if (d == 0 || rng_below(&g->r, 16) >= d + 2) {
+		tc = 0;
+	} else {
+		uint32_t span = rng_below(&g->r, 8) == 0 ? maxnum : (d < maxnum ? d : maxnum);
+		tc = rng_below(&g->r, span + 1);
+	}
+	if (tc > maxnum)
+		tc = maxnum;
+	t1 = rng_below(&g->r, (tc < 3 ? tc : 3) + 1);
+	for (i = 0; i < tc; i++) {
+		int32_t mag;
+		if (i < t1) {
+			mag = 1;
+		} else if (rng_pm(&g->r, g->s->pm_escape)) {
+			mag = 16 + (int32_t)rng_below(&g->r, 3000);
+			if (rng_below(&g->r, 8) == 0)
+				mag = 3000 + (int32_t)rng_below(&g->r, 12000);
+		} else {
+			uint32_t k = rng_below(&g->r, 16);
+			mag = k < 9 ? 1 : k < 13 ? 2 : 3 + (int32_t)rng_below(&g->r, 12);
+		}
+		if (i == t1 && t1 < 3 && mag < 2)
+			mag = 2;
+		lv[i] = rng_below(&g->r, 2) ? -mag : mag;
+	}
+	put_code(w, s_ct[col][t1][tc]);
+	if (tc == 0)
+		return 0;
+	sl = (tc > 10 && t1 < 3) ? 1 : 0;
+	for (i = 0; i < tc; i++) {
+		if (i < t1)
+			bw_u(w, lv[i] < 0, 1);
+		else
+			put_level(w, lv[i], &sl, i == t1 && t1 < 3);
+	}
+	tz = 0;
+	if (tc < maxnum) {
+		tz = rng_below(&g->r, maxnum - tc + 1);
+		if (rng_below(&g->r, 3) == 0)
+			tz = 0;
+		if (maxnum == 4)
+			put_code(w, s_tzc420[tc][tz]);
+		else if (maxnum == 8)
+			put_code(w, s_tzc422[tc][tz]);
+		else
+			put_code(w, s_tz[tc][tz]);
+	}
+	zleft = tz;
+	for (i = 0; i + 1 < tc; i++) {
+		run[i] = 0;
+		if (zleft > 0) {
+			run[i] = rng_below(&g->r, zleft + 1);
+			put_code(w, s_rb[zleft <= 6 ? zleft : 7][run[i]]);
+			zleft -= run[i];
+		}
+	}
+	run[tc - 1] = zleft;
+	if (coefs) {
+		int32_t pos = -1;
+		for (i = tc; i-- > 0;) {
+			pos += (int32_t)run[i] + 1;
+			coefs[pos] = (int16_t)lv[i];
+		}
+	}
+	return tc;
+}
+
+static uint32_t ct_col(uint32_t nc)
+{
+	return nc < 2 ? 0 : nc < 4 ? 1 : nc < 8 ? 2 : 3;
+}
+
+/* residual_luma for one colour component (7.3.5.3.1) */
+static void put_residual_luma(struct gen *g, uint32_t i, uint32_t comp,
+			      int i16, uint32_t cbp_luma, uint8_t *rec)
+{
+	uint8_t *nz = g->nz + (size_t)i * 48 + comp * 16;
+	int16_t *co = rec ? coef_of(rec) + 256 * comp : NULL;
+	uint32_t b;
+	if (i16) {
+		uint32_t nc = neighbour_nc(g, i, comp, 0, 0);
+		nz[0] = (uint8_t)put_block(g, 16, ct_col(nc), co);
+	}
+	for (b = 0; b < 16; b++) {
+		uint32_t nc;
+		if (!(cbp_luma & (1u << (b / 4))))
+			continue;
+		nc = neighbour_nc(g, i, comp, b, 0);
+		if (i16)
+			nz[b] = (uint8_t)put_block(g, 15, ct_col(nc),
+						   co ? co + 16 + 15 * b : NULL);
+		else
+			nz[b] = (uint8_t)put_block(g, 16, ct_col(nc),
+						   co ? co + 16 * b : NULL);
+	}
+}
+
+static void put_residual(struct gen *g, uint32_t i, int i16, uint32_t cbp_luma,
+			 uint32_t cbp_chroma, uint8_t *rec)
+{
+	put_residual_luma(g, i, 0, i16, cbp_luma, rec);
+	if (g->cat == 1 || g->cat == 2) {
+		uint32_t n = g->cat == 1 ? 4 : 8, c, b;
+		int16_t *co = rec ? coef_of(rec) + 256 : NULL;
+		for (c = 0; c < 2; c++) {
+			uint8_t *nz = g->nz + (size_t)i * 48 + (1 + c) * 16;
+			if (cbp_chroma & 3)
+				nz[0] = (uint8_t)put_block(
+					g, n, g->cat == 1 ? 4 : 5,
+					co ? co + n * c : NULL);
+		}
+		for (c = 0; c < 2; c++) {
+			uint8_t *nz = g->nz + (size_t)i * 48 + (1 + c) * 16;
+			if (!(cbp_chroma & 2))
+				continue;
+			for (b = 0; b < n; b++) {
+				uint32_t nc = neighbour_nc(g, i, 1 + c, b, 1);
+				nz[b] = (uint8_t)put_block(
+					g, 15, ct_col(nc),
+					co ? co + 2 * n + 15 * (n * c + b)
+					   : NULL);
+			}
+		}
+	} else if (g->cat == 3) {
+		put_residual_luma(g, i, 1, i16, cbp_luma, rec);
+		put_residual_luma(g, i, 2, i16, cbp_luma, rec);
+	}
+}
+
+static void rec_head(uint8_t *rec, uint32_t mb_type, uint32_t cbp,
+		     uint32_t flags, uint32_t raw, int32_t qpd)
+{
+	if (!rec)
+		return;
+	rec[0] = (uint8_t)mb_type;
+	rec[1] = (uint8_t)cbp;
+	rec[2] = (uint8_t)flags;
+	rec[3] = (uint8_t)raw;
+	rec[4] = (uint8_t)(qpd & 0xff);
+	rec[5] = (uint8_t)((qpd >> 8) & 0xff);
+}
+
+static int32_t pick_qpd(struct gen *g)
+{
+	return rng_below(&g->r, 4) == 0 ? (int32_t)rng_below(&g->r, 13) - 6 : 0;
+}
+
+/* intra macroblock; `base` is the mb_type offset of the slice type */
+static void put_intra_mb(struct gen *g, uint32_t i, uint32_t base, uint8_t *rec)
+{
+	struct bw *w = &g->w;
+	uint32_t n, k, b;
+	if (rng_pm(&g->r, g->s->pm_pcm)) {
+		uint32_t bdl = 8 + g->c->bit_depth_luma_minus8;
+		uint32_t bdc = 8 + g->c->bit_depth_chroma_minus8;
+		uint32_t nch = g->cat == 0 ? 0 : g->cat == 1 ? 64 : g->cat == 2 ? 128 : 256;
+		int zero = rng_pm(&g->r, g->s->pm_zero_pcm);
+		uint16_t *pc = rec ? (uint16_t *)coef_of(rec) : NULL;
+		bw_ue(w, base + 25);
+		while (w->nbits != 0)
+			bw_u(w, 0, 1);
+		for (k = 0; k < 256 + 2 * nch; k++) {
+			uint32_t bd = k < 256 ? bdl : bdc;
+			uint32_t v = zero ? (rng_below(&g->r, 64) == 0 ? rng_below(&g->r, 4) : 0)
+					  : rng_below(&g->r, 1u << bd);
+			bw_u(w, v, (int)bd);
+			if (pc)
+				pc[k] = (uint16_t)v;
+		}
+		memset(g->nz + (size_t)i * 48, 16, 48);
+		rec_head(rec, MB_I_PCM, 0, 0, base + 25, 0);
+		return;
+	}
+	if (rng_pm(&g->r, g->s->pm_i16x16)) {
+		uint32_t pred = rng_below(&g->r, 4);
+		uint32_t chroma = (g->cat == 1 || g->cat == 2) ? rng_below(&g->r, 3) : 0;
+		uint32_t luma = rng_below(&g->r, 2) ? 15 : 0;
+		uint32_t t = 1 + pred + 4 * chroma + (luma ? 12 : 0);
+		uint32_t icp = 0;
+		int32_t qpd = pick_qpd(g);
+		bw_ue(w, base + t);
+		if (g->cat == 1 || g->cat == 2) {
+			icp = rng_below(&g->r, 4);
+			bw_ue(w, icp);
+		}
+		bw_se(w, qpd);
+		rec_head(rec, MB_I_16x16, luma | (chroma << 4), 0, base + t, qpd);
+		if (rec) {
+			rec[6] = (uint8_t)icp;
+			rec[7] = (uint8_t)pred;
+		}
+		put_residual(g, i, 1, luma, chroma, rec);
+		return;
+	}
+	/* I_NxN */
+	{
+		int t8 = g->c->transform_8x8_mode_flag &&
+			 rng_pm(&g->r, g->s->pm_t8x8);
+		uint32_t luma, chroma, cbp, icp = 0;
+		int32_t qpd = 0;
+		int no_res = rng_pm(&g->r, g->s->pm_cbp_zero);
+		bw_ue(w, base + 0);
+		if (g->c->transform_8x8_mode_flag)
+			bw_u(w, (uint32_t)t8, 1);
+		n = t8 ? 4 : 16;
+		for (b = 0; b < n; b++) {
+			if (rng_below(&g->r, 2)) {
+				bw_u(w, 1, 1);
+			} else {
+				uint32_t m = rng_below(&g->r, 8);
+				bw_u(w, 0, 1);
+				bw_u(w, m, 3);
+				if (rec)
+					rec[8 + b / 2] |= (uint8_t)((m + 1) << (4 * (b & 1)));
+			}
+		}
+		if (g->cat == 1 || g->cat == 2) {
+			icp = rng_below(&g->r, 4);
+			bw_ue(w, icp);
+		}
+		luma = no_res ? 0 : rng_below(&g->r, 16);
+		chroma = (no_res || !(g->cat == 1 || g->cat == 2)) ? 0 : rng_below(&g->r, 3);
+		cbp = luma | (chroma << 4);
+		bw_ue(w, s_cbp_code[(g->cat == 1 || g->cat == 2) ? 0 : 1][0][cbp]);
+		if (cbp) {
+			qpd = pick_qpd(g);
+			bw_se(w, qpd);
+		}
+		rec_head(rec, MB_I_NxN, cbp, t8 ? MBF_T8X8 : 0, base + 0, qpd);
+		if (rec)
+			rec[6] = (uint8_t)icp;
+		if (cbp)
+			put_residual(g, i, 0, luma, chroma, rec);
+	}
+}
+
+static void put_mvd(struct gen *g, int16_t *dst)
+{
+	uint32_t c;
+	for (c = 0; c < 2; c++) {
+		int32_t v = rng_below(&g->r, 3) == 0
+				    ? 0
+				    : (int32_t)rng_below(&g->r, 65) - 32;
+		if (rng_below(&g->r, 64) == 0)
+			v = (int32_t)rng_below(&g->r, 4001) - 2000;
+		bw_se(&g->w, v);
+		if (dst)
+			dst[c] = (int16_t)v;
+	}
+}
+
+/* inter macroblock of a P or B slice (7.3.5.1, 7.3.5.2) */
+static void put_inter_mb(struct gen *g, uint32_t i, uint8_t *rec)
+{
+	struct bw *w = &g->w;
+	int isb = g->st == 1;
+	uint32_t t, nparts, p, s, mbt;
+	uint32_t pm[4] = {0, 0, 0, 0};
+	uint32_t sub[4] = {0, 0, 0, 0}, nsub[4] = {1, 1, 1, 1};
+	int no_sub8 = 1, t8 = 0;
+	uint32_t luma, chroma, cbp;
+	int32_t qpd = 0;
+	int16_t *mv0 = rec ? (int16_t *)(rec + 128) : NULL;
+	int16_t *mv1 = rec ? (int16_t *)(rec + 192) : NULL;
+	static const uint8_t bpm[18][2] = {
+		{PM_L0, PM_L0}, {PM_L0, PM_L0}, {PM_L1, PM_L1}, {PM_L1, PM_L1},
+		{PM_L0, PM_L1}, {PM_L0, PM_L1}, {PM_L1, PM_L0}, {PM_L1, PM_L0},
+		{PM_L0, PM_BI}, {PM_L0, PM_BI}, {PM_L1, PM_BI}, {PM_L1, PM_BI},
+		{PM_BI, PM_L0}, {PM_BI, PM_L0}, {PM_BI, PM_L1}, {PM_BI, PM_L1},
+		{PM_BI, PM_BI}, {PM_BI, PM_BI}};
+	static const uint8_t bsub_pm[13] = {PM_DIRECT, PM_L0, PM_L1, PM_BI, PM_L0,
+					    PM_L0, PM_L1, PM_L1, PM_BI, PM_BI,
+					    PM_L0, PM_L1, PM_BI};
+	static const uint8_t bsub_n[13] = {4, 1, 1, 1, 2, 2, 2, 2, 2, 2, 4, 4, 4};
+	static const uint8_t psub_n[4] = {1, 2, 2, 4};
+
+	if (!isb) {
+		t = rng_below(&g->r, 5);
+		nparts = t == 0 ? 1 : t <= 2 ? 2 : 4;
+		mbt = MB_P_16x16 + t;
+		for (p = 0; p < nparts; p++)
+			pm[p] = PM_L0;
+	} else {
+		t = rng_below(&g->r, 23);
+		if (t == 0) {
+			nparts = 1;
+			pm[0] = PM_DIRECT;
+			mbt = MB_B_Direct_16x16;
+		} else if (t <= 3) {
+			nparts = 1;
+			pm[0] = t;
+			mbt = MB_B_16x16;
+		} else if (t <= 21) {
+			nparts = 2;
+			pm[0] = bpm[t - 4][0];
+			pm[1] = bpm[t - 4][1];
+			mbt = (t & 1) ? MB_B_8x16 : MB_B_16x8;
+		} else {
+			nparts = 4;
+			mbt = MB_B_8x8;
+		}
+	}
+	bw_ue(w, t);
+
+	if (nparts == 4) {
+		for (p = 0; p < 4; p++) {
+			sub[p] = rng_below(&g->r, isb ? 13 : 4);
+			bw_ue(w, sub[p]);
+			if (isb) {
+				pm[p] = bsub_pm[sub[p]];
+				nsub[p] = bsub_n[sub[p]];
+			} else {
+				pm[p] = PM_L0;
+				nsub[p] = psub_n[sub[p]];
+			}
+			if (pm[p] != PM_DIRECT) {
+				if (nsub[p] > 1)
+					no_sub8 = 0;
+			} else if (!g->c->direct_8x8_inference_flag) {
+				no_sub8 = 0;
+			}
+			if (rec)
+				rec[8 + p] = (uint8_t)sub[p];
+		}
+		if (g->nref0 > 0 && mbt != MB_P_8x8ref0) {
+			for (p = 0; p < 4; p++)
+				if (pm[p] != PM_DIRECT && pm[p] != PM_L1) {
+					uint32_t v = rng_below(&g->r, g->nref0 + 1);
+					bw_te(w, v, g->nref0);
+					if (rec)
+						rec[64 + p] = (uint8_t)v;
+				}
+		}
+		if (g->nref1 > 0) {
+			for (p = 0; p < 4; p++)
+				if (pm[p] != PM_DIRECT && pm[p] != PM_L0) {
+					uint32_t v = rng_below(&g->r, g->nref1 + 1);
+					bw_te(w, v, g->nref1);
+					if (rec)
+						rec[68 + p] = (uint8_t)v;
+				}
+		}
+		for (p = 0; p < 4; p++)
+			if (pm[p] != PM_DIRECT && pm[p] != PM_L1)
+				for (s = 0; s < nsub[p]; s++)
+					put_mvd(g, mv0 ? mv0 + 8 * p + 2 * s : NULL);
+		for (p = 0; p < 4; p++)
+			if (pm[p] != PM_DIRECT && pm[p] != PM_L0)
+				for (s = 0; s < nsub[p]; s++)
+					put_mvd(g, mv1 ? mv1 + 8 * p + 2 * s : NULL);
+	} else if (pm[0] != PM_DIRECT) {
+		if (g->nref0 > 0)
+			for (p = 0; p < nparts; p++)
+				if (pm[p] != PM_L1) {
+					uint32_t v = rng_below(&g->r, g->nref0 + 1);
+					bw_te(w, v, g->nref0);
+					if (rec)
+						rec[64 + p] = (uint8_t)v;
+				}
+		if (g->nref1 > 0)
+			for (p = 0; p < nparts; p++)
+				if (pm[p] != PM_L0) {
+					uint32_t v = rng_below(&g->r, g->nref1 + 1);
+					bw_te(w, v, g->nref1);
+					if (rec)
+						rec[68 + p] = (uint8_t)v;
+				}
+		for (p = 0; p < nparts; p++)
+			if (pm[p] != PM_L1)
+				put_mvd(g, mv0 ? mv0 + 8 * p : NULL);
+		for (p = 0; p < nparts; p++)
+			if (pm[p] != PM_L0)
+				put_mvd(g, mv1 ? mv1 + 8 * p : NULL);
+	}
+
+	if (rng_pm(&g->r, g->s->pm_cbp_zero)) {
+		luma = chroma = 0;
+	} else {
+		luma = rng_below(&g->r, 16);
+		chroma = (g->cat == 1 || g->cat == 2) ? rng_below(&g->r, 3) : 0;
+	}
+	cbp = luma | (chroma << 4);
+	bw_ue(w, s_cbp_code[(g->cat == 1 || g->cat == 2) ? 0 : 1][1][cbp]);
+	if (luma > 0 && g->c->transform_8x8_mode_flag && no_sub8 &&
+	    (mbt != MB_B_Direct_16x16 || g->c->direct_8x8_inference_flag)) {
+		t8 = rng_pm(&g->r, g->s->pm_t8x8);
+		bw_u(w, (uint32_t)t8, 1);
+	}
+	if (cbp) {
+		qpd = pick_qpd(g);
+		bw_se(w, qpd);
+	}
+	rec_head(rec, mbt, cbp, t8 ? MBF_T8X8 : 0, t, qpd);
+	if (cbp)
+		put_residual(g, i, 0, luma, chroma, rec);
+}
+
+/* ---- slice header (7.3.3) ------------------------------------------------ */
+static void put_slice_header(struct gen *g)
+{
+	const struct h264gen_cfg *c = g->c;
+	const struct h264gen_slice *s = g->s;
+	struct bw *w = &g->w;
+	uint32_t i;
+	bw_u(w, (s->nal_ref_idc << 5) | (s->idr ? 5 : 1), 8);
+	bw_ue(w, s->first_mb);
+	bw_ue(w, s->slice_type);
+	bw_ue(w, c->pps_id);
+	bw_u(w, s->frame_num, (int)c->log2_max_frame_num_minus4 + 4);
+	if (s->idr)
+		bw_ue(w, s->idr_pic_id);
+	if (c->pic_order_cnt_type == 0) {
+		bw_u(w, s->poc_lsb, (int)c->log2_max_poc_lsb_minus4 + 4);
+		if (c->bottom_field_pic_order_in_frame_present_flag)
+			bw_se(w, 0);
+	}
+	if (c->redundant_pic_cnt_present_flag)
+		bw_ue(w, 0);
+	if (g->st == 1)
+		bw_u(w, 1, 1); /* direct_spatial_mv_pred_flag */
+	if (g->st == 0 || g->st == 1) {
+		if (s->hdr_extras & H264GEN_HDR_OVERRIDE) {
+			bw_u(w, 1, 1);
+			bw_ue(w, s->num_ref_idx_l0_minus1);
+			if (g->st == 1)
+				bw_ue(w, s->num_ref_idx_l1_minus1);
+		} else {
+			bw_u(w, 0, 1);
+		}
+		/* ref_pic_list_modification */
+		for (i = 0; i < (g->st == 1 ? 2u : 1u); i++) {
+			if (s->hdr_extras & H264GEN_HDR_RPLM) {
+				bw_u(w, 1, 1);
+				bw_ue(w, 0);
+				bw_ue(w, rng_below(&g->r, 4));
+				bw_ue(w, 1);
+				bw_ue(w, rng_below(&g->r, 4));
+				bw_ue(w, 2);
+				bw_ue(w, rng_below(&g->r, 3));
+				bw_ue(w, 3);
+			} else {
+				bw_u(w, 0, 1);
+			}
+		}
+	}
+	if ((c->weighted_pred_flag && g->st == 0) ||
+	    (c->weighted_bipred_idc == 1 && g->st == 1)) {
+		uint32_t l, k;
+		bw_ue(w, rng_below(&g->r, 8)); /* luma_log2_weight_denom */
+		if (g->cat != 0)
+			bw_ue(w, rng_below(&g->r, 8));
+		for (l = 0; l < (g->st == 1 ? 2u : 1u); l++) {
+			uint32_t n = (l == 0 ? g->nref0 : g->nref1) + 1;
+			for (k = 0; k < n; k++) {
+				int f = (int)rng_below(&g->r, 2);
+				bw_u(w, (uint32_t)f, 1);
+				if (f) {
+					bw_se(w, (int32_t)rng_below(&g->r, 256) - 128);
+					bw_se(w, (int32_t)rng_below(&g->r, 256) - 128);
+				}
+				if (g->cat != 0) {
+					f = (int)rng_below(&g->r, 2);
+					bw_u(w, (uint32_t)f, 1);
+					if (f) {
+						bw_se(w, (int32_t)rng_below(&g->r, 256) - 128);
+						bw_se(w, (int32_t)rng_below(&g->r, 256) - 128);
+						bw_se(w, (int32_t)rng_below(&g->r, 256) - 128);
+						bw_se(w, (int32_t)rng_below(&g->r, 256) - 128);
+					}
+				}
+			}
+		}
+	}
+	if (s->nal_ref_idc != 0) {
+		if (s->idr) {
+			bw_u(w, 0, 1);
+			bw_u(w, 0, 1);
+		} else if (s->hdr_extras & H264GEN_HDR_MMCO) {
+			bw_u(w, 1, 1);
+			bw_ue(w, 1);
+			bw_ue(w, rng_below(&g->r, 4));
+			bw_ue(w, 3);
+			bw_ue(w, rng_below(&g->r, 4));
+			bw_ue(w, rng_below(&g->r, 2));
+			bw_ue(w, 2);
+			bw_ue(w, rng_below(&g->r, 4));
+			bw_ue(w, 4);
+			bw_ue(w, rng_below(&g->r, 3));
+			bw_ue(w, 6);
+			bw_ue(w, rng_below(&g->r, 2));
+			bw_ue(w, 0);
+		} else {
+			bw_u(w, 0, 1);
+		}
+	}
+	if (c->entropy_coding_mode_flag && g->st != 2 && g->st != 4)
+		bw_ue(w, s->cabac_init_idc);
+	bw_se(w, s->slice_qp_delta);
+	if (c->deblocking_filter_control_present_flag) {
+		bw_ue(w, s->disable_deblocking_filter_idc);
+		if (s->disable_deblocking_filter_idc != 1) {
+			bw_se(w, s->alpha_c0_offset_div2);
+			bw_se(w, s->beta_offset_div2);
+		}
+	}
+}
+
+size_t h264gen_slice_bound(const struct h264gen_cfg *cfg,
+			   const struct h264gen_slice *sl)
+{
+	uint32_t cat = chroma_array_type(cfg);
+	/* worst case is all-PCM at full bit depth, escapes doubled */
+	size_t per_mb = (size_t)(256 + (cat == 0 ? 0 : cat == 1 ? 128 : cat == 2 ? 256 : 512)) * 2 * 2 + 64;
+	if (sl->pm_pcm == 0 && sl->pm_escape == 0)
+		per_mb = 48 * 16 * 2 + 256; /* dense small levels */
+	else if (sl->pm_pcm == 0)
+		per_mb = 48 * 16 * 6 + 256;
+	return 1024 + (size_t)sl->num_mbs * per_mb + sl->cabac_payload * 2;
+}
+
+int h264gen_slice_nal(const struct h264gen_cfg *cfg,
+		      const struct h264gen_slice *sl, uint8_t *out, size_t cap,
+		      uint8_t *t2, uint32_t t2_stride)
+{
+	struct gen g;
+	uint32_t i, run = 0;
+	pthread_once(&s_once, tables_init);
+	if (cfg->width_mbs == 0 || sl->num_mbs == 0)
+		return -EINVAL;
+	memset(&g, 0, sizeof(g));
+	g.c = cfg;
+	g.s = sl;
+	g.r.s = sl->seed * 0x9E3779B97F4A7C15ull + 0x1234567ull;
+	if (g.r.s == 0)
+		g.r.s = 1;
+	g.cat = chroma_array_type(cfg);
+	g.W = cfg->width_mbs;
+	g.st = sl->slice_type % 5;
+	g.nref0 = (sl->hdr_extras & H264GEN_HDR_OVERRIDE)
+			  ? sl->num_ref_idx_l0_minus1
+			  : cfg->num_ref_idx_l0_default_minus1;
+	g.nref1 = ((sl->hdr_extras & H264GEN_HDR_OVERRIDE) && g.st == 1)
+			  ? sl->num_ref_idx_l1_minus1
+			  : cfg->num_ref_idx_l1_default_minus1;
+	g.t2 = t2;
+	g.t2_stride = t2_stride;
+	bw_init(&g.w, out, cap);
+	put_slice_header(&g);
+
+	if (cfg->entropy_coding_mode_flag) {
+		/* opaque CABAC payload: the reader only records its extent */
+		while (g.w.nbits != 0)
+			bw_u(&g.w, 1, 1);
+		for (i = 0; i < sl->cabac_payload; i++)
+			bw_u(&g.w, rng_below(&g.r, 6) == 0 ? 0 : rng_below(&g.r, 256), 8);
+		bw_u(&g.w, 0x80, 8);
+		return finish(&g.w);
+	}
+
+	g.nz = calloc((size_t)sl->num_mbs, 48);
+	if (g.nz == NULL)
+		return -ENOMEM;
+	if (t2)
+		memset(t2, 0, (size_t)sl->num_mbs * t2_stride);
+	for (i = 0; i < sl->num_mbs; i++) {
+		uint8_t *rec = rec_of(&g, i);
+		if (g.st == 2) {
+			put_intra_mb(&g, i, 0, rec);
+			if (rec)
+				memcpy(rec + 16, g.nz + (size_t)i * 48, 48);
+			continue;
+		}
+		/* P / B */
+		{
+			int last = i + 1 == sl->num_mbs;
+			int skip = rng_pm(&g.r, sl->pm_skip);
+			if (last)
+				skip = sl->end_with_skip ? 1 : 0;
+			if (skip) {
+				run++;
+				rec_head(rec, g.st == 1 ? MB_B_SKIP : MB_P_SKIP,
+					 0, MBF_SKIPPED, 0, 0);
+				if (last)
+					bw_ue(&g.w, run);
+				continue;
+			}
+			bw_ue(&g.w, run);
+			run = 0;
+			if (rng_pm(&g.r, sl->pm_intra_in_inter))
+				put_intra_mb(&g, i, g.st == 1 ? 23 : 5, rec);
+			else
+				put_inter_mb(&g, i, rec);
+			if (rec)
+				memcpy(rec + 16, g.nz + (size_t)i * 48, 48);
+		}
+	}
+	bw_trailing(&g.w);
+	free(g.nz);
+	return finish(&g.w);
+}
+
+/* ---- threaded batch ------------------------------------------------------ */
+struct batch {
+	const struct h264gen_cfg *cfg;
+	const struct h264gen_slice *slices;
+	uint32_t n, first, step;
+	uint8_t *out;
+	const uint64_t *offs;
+	uint32_t *sizes;
+	const size_t *caps;
+	int err;
+};
+
+static void *batch_worker(void *arg)
+{
+	struct batch *b = arg;
+	uint32_t i;
+	for (i = b->first; i < b->n; i += b->step) {
+		int r = h264gen_slice_nal(b->cfg, &b->slices[i],
+					  b->out + b->offs[i], b->caps[i], NULL,
+					  0);
+		if (r < 0) {
+			b->err = r;
+			b->sizes[i] = 0;
+		} else {
+			b->sizes[i] = (uint32_t)r;
+		}
+	}
+	return NULL;
+}
+
+/* Two passes: slots sized by the bound, then compacted in order. */
+long h264gen_batch(const struct h264gen_cfg *cfg,
+		   const struct h264gen_slice *slices, uint32_t n, int threads,
+		   uint8_t *out, size_t cap, uint64_t *offs, uint32_t *sizes)
+{
+	struct batch *jobs;
+	pthread_t *tids;
+	size_t *caps;
+	uint64_t pos = 0;
+	uint32_t i;
+	int t, err = 0;
+	if (threads < 1)
+		threads = 1;
+	caps = calloc(n ? n : 1, sizeof(*caps));
+	jobs = calloc((size_t)threads, sizeof(*jobs));
+	tids = calloc((size_t)threads, sizeof(*tids));
+	if (!caps || !jobs || !tids)
+		return -ENOMEM;
+	for (i = 0; i < n; i++) {
+		caps[i] = (h264gen_slice_bound(cfg, &slices[i]) + 15) & ~(size_t)15;
+		offs[i] = pos;
+		pos += caps[i];
+	}
+	if (pos > cap) {
+		free(caps);
+		free(jobs);
+		free(tids);
+		return -ENOBUFS;
+	}
+	for (t = 0; t < threads; t++) {
+		jobs[t].cfg = cfg;
+		jobs[t].slices = slices;
+		jobs[t].n = n;
+		jobs[t].first = (uint32_t)t;
+		jobs[t].step = (uint32_t)threads;
+		jobs[t].out = out;
+		jobs[t].offs = offs;
+		jobs[t].sizes = sizes;
+		jobs[t].caps = caps;
+		pthread_create(&tids[t], NULL, batch_worker, &jobs[t]);
+	}
+	for (t = 0; t < threads; t++) {
+		pthread_join(tids[t], NULL);
+		if (jobs[t].err)
+			err = jobs[t].err;
+	}
+	/* compact to 16-byte aligned, back-to-back layout */
+	pos = 0;
+	for (i = 0; i < n && !err; i++) {
+		if (offs[i] != pos)
+			memmove(out + pos, out + offs[i], sizes[i]);
+		offs[i] = pos;
+		pos = (pos + sizes[i] + 15) & ~(uint64_t)15;
+	}
+	free(caps);
+	free(jobs);
+	free(tids);
+	return err ? err : (long)pos;
+}
