@@ -163,11 +163,13 @@ struct h264_amd_slice_result {
  * so the sum can be taken over any partition of the record, in any order. */
 static inline uint64_t h264_amd_checksum_term(uint32_t idx, uint16_t word)
 {
+	/* both multipliers are affine in idx so that a kernel can step them
+	 * from macroblock to macroblock with one add */
 	uint32_t a = idx * 0x9E3779B1u + 0x85EBCA77u;
-	uint32_t b = (idx ^ 0x5BD1E995u) * 0xC2B2AE3Du + 0x27D4EB2Fu;
+	uint32_t b = idx * 0xC2B2AE3Du + 0x27D4EB2Fu;
 	uint32_t w = word;
 	uint32_t lo = w * a;
-	uint32_t hi = (w * w + w) * b;
+	uint32_t hi = (w * (w + 1u)) * b;
 	return ((uint64_t)hi << 32) | lo;
 }
 /* the two 32-bit halves are summed independently (no carry between them) */

@@ -1,0 +1,109 @@
+"""Build the native parts of libh264_amd in-tree.
+
+  libh264_amd/lib/libh264_amd_engine.so   HIP kernels + C-ABI shim (hipcc, gfx950)
+  libh264_amd/lib/libh264.so              drop-in libh264 C API (plain C host
+                                          code linked against the engine)
+  libh264_amd/lib/libh264gen.so           synthetic stream generator (gcc)
+
+hipcc cross-compiles for gfx950 without a GPU.  The .so files are git-ignored
+but travel to the GPU box with the source snapshot.
+"""
+import os
+import shutil
+import subprocess
+import sys
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+ROOT = os.path.dirname(HERE)
+CSRC = os.path.join(HERE, "csrc")
+LIB = os.path.join(HERE, "lib")
+INC = os.path.join(ROOT, "include")
+
+
+def _hipcc():
+    for cand in (os.environ.get("HIPCC"), "/opt/rocm/bin/hipcc",
+                 shutil.which("hipcc")):
+        if cand and os.path.exists(cand):
+            return cand
+    raise RuntimeError("hipcc not found")
+
+
+def _newer(target, sources):
+    if not os.path.exists(target):
+        return True
+    t = os.path.getmtime(target)
+    for s in sources:
+        if os.path.getmtime(s) > t:
+            return True
+    return False
+
+
+def _tree(*dirs):
+    out = []
+    for d in dirs:
+        for base, _dirs, files in os.walk(d):
+            for f in files:
+                if f.endswith((".c", ".h", ".hip", ".inc", ".cpp")):
+                    out.append(os.path.join(base, f))
+    return out
+
+
+def _run(cmd):
+    print("+", " ".join(cmd), file=sys.stderr)
+    subprocess.check_call(cmd)
+
+
+def build_gen(force=False):
+    out = os.path.join(LIB, "libh264gen.so")
+    srcs = _tree(os.path.join(CSRC, "gen"), os.path.join(CSRC, "common"))
+    if force or _newer(out, srcs):
+        _run(["gcc", "-std=gnu99", "-O2", "-fPIC", "-shared", "-Wall",
+              os.path.join(CSRC, "gen", "h264gen.c"), "-o", out, "-lpthread"])
+    return out
+
+
+def build_engine(force=False):
+    out = os.path.join(LIB, "libh264_amd_engine.so")
+    srcs = _tree(CSRC, INC)
+    if force or _newer(out, srcs):
+        _run([_hipcc(), "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC",
+              "-shared", "-Wno-unused-value", "-I" + INC, "-I" + CSRC,
+              os.path.join(CSRC, "engine.hip"), "-o", out])
+    return out
+
+
+def build_host(force=False):
+    """The drop-in C library: plain C objects linked with the engine."""
+    out = os.path.join(LIB, "libh264.so")
+    hostdir = os.path.join(CSRC, "host")
+    if not os.path.isdir(hostdir):
+        return None
+    csrcs = sorted(os.path.join(hostdir, f) for f in os.listdir(hostdir)
+                   if f.endswith(".c"))
+    if not csrcs:
+        return None
+    srcs = _tree(hostdir, INC)
+    if force or _newer(out, srcs + [build_engine()]):
+        objs = []
+        objdir = os.path.join(LIB, "obj")
+        os.makedirs(objdir, exist_ok=True)
+        for c in csrcs:
+            o = os.path.join(objdir, os.path.basename(c)[:-2] + ".o")
+            _run(["gcc", "-std=gnu99", "-D_GNU_SOURCE", "-DH264_API_EXPORTS",
+                  "-fvisibility=hidden", "-O2", "-fPIC", "-Wall",
+                  "-I" + INC, "-I" + CSRC, "-c", c, "-o", o])
+            objs.append(o)
+        _run(["gcc", "-shared", "-o", out] + objs +
+             ["-L" + LIB, "-lh264_amd_engine", "-Wl,-rpath,$ORIGIN",
+              "-lpthread"])
+    return out
+
+
+def build_all(force=False):
+    os.makedirs(LIB, exist_ok=True)
+    return {"gen": build_gen(force), "engine": build_engine(force),
+            "host": build_host(force)}
+
+
+if __name__ == "__main__":
+    print(build_all(force="--force" in sys.argv))

@@ -1,0 +1,565 @@
+/**
+ * engine.hip -- C-ABI shim of the batched MI355X engine (<h264_amd.h>).
+ *
+ * Thin host layer: owns the HIP stream, the lane-table image, the compact
+ * parameter-set snapshots and the scratch the kernels need; every entry point
+ * validates its arguments, makes sure the device-side tables are current and
+ * launches one hand-written gfx950 kernel.  No parsing happens here and there
+ * is no CPU fallback: if HIP cannot give us a gfx950 device the calls return
+ * -ENODEV.
+ *
+ * The kernels are compiled into this translation unit (no -fgpu-rdc needed).
+ */
+#include <hip/hip_runtime.h>
+
+#include <errno.h>
+#include <stdint.h>
+#include <stdio.h>
+#include <string.h>
+
+#include <new>
+#include <vector>
+
+#define H264_API_EXPORTS 1
+#include <h264_amd.h>
+
+#include "kernels/dev_params.h"
+#include "kernels/scan.hip"
+#include "kernels/slice_decode.hip"
+#include "kernels/slice_write.hip"
+
+/* ---- helpers --------------------------------------------------------------- */
+
+static int hip_err(hipError_t e)
+{
+	switch (e) {
+	case hipSuccess:
+		return 0;
+	case hipErrorOutOfMemory:
+		return -ENOMEM;
+	case hipErrorInvalidValue:
+	case hipErrorInvalidDevicePointer:
+		return -EINVAL;
+	case hipErrorNoDevice:
+	case hipErrorInvalidDevice:
+	case hipErrorNoBinaryForGpu:
+	case hipErrorInvalidDeviceFunction:
+		return -ENODEV;
+	default:
+		return -EIO;
+	}
+}
+
+#define HIP_TRY(x)                                                             \
+	do {                                                                   \
+		hipError_t _e = (x);                                           \
+		if (_e != hipSuccess) {                                        \
+			fprintf(stderr, "libh264_amd: %s failed: %s\n", #x,    \
+				hipGetErrorString(_e));                        \
+			return hip_err(_e);                                    \
+		}                                                              \
+	} while (0)
+
+enum { FAM_SCAN, FAM_DECODE, FAM_WRITE, FAM_SYNTH, FAM_COUNT };
+
+struct h264_amd_params {
+	std::vector<h264_sps> sps_full;
+	std::vector<h264_pps> pps_full;
+	std::vector<dev_sps> sps;
+	std::vector<dev_pps> pps;
+	std::vector<dev_epoch> epochs;
+	uint64_t serial; /* bumped on every change */
+	uint32_t max_width_mbs, max_pic_mbs;
+};
+
+struct h264_amd_engine {
+	int device;
+	hipStream_t stream;
+	bool own_stream;
+	dev_vlc_tables *d_vlc;
+	cabac_tables *d_cabac;
+	/* device copy of the last params object used */
+	const h264_amd_params *params_src;
+	uint64_t params_serial;
+	dev_sps *d_sps;
+	dev_pps *d_pps;
+	dev_epoch *d_epochs;
+	size_t cap_sps, cap_pps, cap_epochs;
+	hipEvent_t ev[FAM_COUNT][2];
+	bool timed[FAM_COUNT];
+	/* scan scratch */
+	scan_scratch scan;
+};
+
+/* ---- lane tables from the standard's bit strings -------------------------- */
+
+struct code_word {
+	uint32_t mask, code, len;
+};
+
+static code_word parse_bits(const char *s)
+{
+	code_word c = {0, 0, 0};
+	uint32_t v = 0;
+	for (; *s; s++) {
+		if (*s == '0' || *s == '1') {
+			v = (v << 1) | (uint32_t)(*s - '0');
+			c.len++;
+		}
+	}
+	c.mask = c.len ? 0xffffffffu << (32 - c.len) : 0;
+	c.code = c.len ? v << (32 - c.len) : 0;
+	return c;
+}
+
+static void put_word(dev_vlc_tables *t, int row, uint32_t lane, const char *bits)
+{
+	code_word c = parse_bits(bits);
+	t->e[row][lane] = c.mask;
+	t->e[row + 1][lane] = c.code;
+}
+
+/* Layout documented in kernels/vlc_lanes.hip.h */
+static void vlc_build_tables(dev_vlc_tables *t)
+{
+	uint32_t next[6] = {0, 0, 0, 0, 0, 16};
+	for (int r = 0; r < DEV_VLC_TABLES; r++)
+		for (int l = 0; l < 64; l++)
+			t->e[r][l] = 0;
+	/* unused lanes: mask 0 / code 1 never matches */
+	for (int r = 0; r < 22; r++) {
+		bool is_code_row = r < 12 ? (r % 3) == 1 : ((r - 12) % 2) == 1;
+		if (is_code_row)
+			for (int l = 0; l < 64; l++)
+				t->e[r][l] = 1;
+	}
+#define H264_CT(col, bits, t1, tc)                                             \
+	do {                                                                   \
+		if ((col) != 3) {                                              \
+			int row = (col) <= 2 ? 3 * (col) : 9;                  \
+			uint32_t lane = next[col]++;                           \
+			put_word(t, row, lane, bits);                          \
+			t->e[row + 2][lane] = ((t1) << 5) | (tc);              \
+		}                                                              \
+	} while (0);
+#define H264_TZ(idx, bits, v)                                                  \
+	do {                                                                   \
+		uint32_t cum = 17u * ((idx)-1u) - (idx) * ((idx)-1u) / 2u;     \
+		int row = (idx) <= 4 ? 12 : (idx) <= 9 ? 14 : 16;              \
+		uint32_t base = (idx) <= 4 ? cum                               \
+				: (idx) <= 9 ? cum - 58u                       \
+					     : cum - 108u;                     \
+		put_word(t, row, base + (v), bits);                            \
+	} while (0);
+#define H264_TZ_C420(idx, bits, v)                                             \
+	put_word(t, 18, 5u * ((idx)-1u) - (idx) * ((idx)-1u) / 2u + (v), bits);
+#define H264_TZ_C422(idx, bits, v)                                             \
+	put_word(t, 18, 16u + 9u * ((idx)-1u) - (idx) * ((idx)-1u) / 2u + (v), bits);
+#define H264_RB(idx, bits, v)                                                  \
+	put_word(t, 20, ((idx)-1u) * ((idx) + 2u) / 2u + (v), bits);
+#define H264_CBP(cls, code, intra, inter)                                      \
+	t->e[22][code] |= ((uint32_t)(intra) << (16 * (cls))) |                \
+			  ((uint32_t)(inter) << (16 * (cls) + 8));
+#include "common/h264_cavlc_tables.inc"
+#undef H264_CT
+#undef H264_TZ
+#undef H264_TZ_C420
+#undef H264_TZ_C422
+#undef H264_RB
+#undef H264_CBP
+}
+
+/* ---- engine ----------------------------------------------------------------- */
+
+extern "C" int h264_amd_available(void)
+{
+	int n = 0;
+	if (hipGetDeviceCount(&n) != hipSuccess)
+		return 0;
+	return n > 0;
+}
+
+extern "C" int h264_amd_engine_new(int device, void *hip_stream,
+				   struct h264_amd_engine **ret)
+{
+	if (ret == NULL)
+		return -EINVAL;
+	*ret = NULL;
+	int n = 0;
+	if (hipGetDeviceCount(&n) != hipSuccess || device < 0 || device >= n)
+		return -ENODEV;
+	HIP_TRY(hipSetDevice(device));
+	hipDeviceProp_t prop;
+	HIP_TRY(hipGetDeviceProperties(&prop, device));
+	if (strncmp(prop.gcnArchName, "gfx950", 6) != 0) {
+		fprintf(stderr,
+			"libh264_amd: device %d is %s, kernels are built for gfx950\n",
+			device, prop.gcnArchName);
+		return -ENODEV;
+	}
+	h264_amd_engine *e = new (std::nothrow) h264_amd_engine();
+	if (e == NULL)
+		return -ENOMEM;
+	memset(e, 0, sizeof(*e));
+	e->device = device;
+	if (hip_stream != NULL) {
+		e->stream = (hipStream_t)hip_stream;
+	} else {
+		HIP_TRY(hipStreamCreateWithFlags(&e->stream, hipStreamNonBlocking));
+		e->own_stream = true;
+	}
+	for (int f = 0; f < FAM_COUNT; f++)
+		for (int k = 0; k < 2; k++)
+			HIP_TRY(hipEventCreate(&e->ev[f][k]));
+	{
+		dev_vlc_tables *h = new dev_vlc_tables;
+		vlc_build_tables(h);
+		HIP_TRY(hipMalloc((void **)&e->d_vlc, sizeof(*h)));
+		HIP_TRY(hipMemcpy(e->d_vlc, h, sizeof(*h), hipMemcpyHostToDevice));
+		delete h;
+	}
+	{
+		cabac_tables *h = new cabac_tables;
+		cabac_build_tables(h);
+		HIP_TRY(hipMalloc((void **)&e->d_cabac, sizeof(*h)));
+		HIP_TRY(hipMemcpy(e->d_cabac, h, sizeof(*h), hipMemcpyHostToDevice));
+		delete h;
+	}
+	*ret = e;
+	return 0;
+}
+
+extern "C" int h264_amd_engine_destroy(struct h264_amd_engine *e)
+{
+	if (e == NULL)
+		return 0;
+	hipSetDevice(e->device);
+	hipStreamSynchronize(e->stream);
+	for (int f = 0; f < FAM_COUNT; f++)
+		for (int k = 0; k < 2; k++)
+			hipEventDestroy(e->ev[f][k]);
+	hipFree(e->d_vlc);
+	hipFree(e->d_cabac);
+	hipFree(e->d_sps);
+	hipFree(e->d_pps);
+	hipFree(e->d_epochs);
+	scan_scratch_free(&e->scan);
+	if (e->own_stream)
+		hipStreamDestroy(e->stream);
+	delete e;
+	return 0;
+}
+
+extern "C" int h264_amd_engine_sync(struct h264_amd_engine *e)
+{
+	if (e == NULL)
+		return -EINVAL;
+	HIP_TRY(hipStreamSynchronize(e->stream));
+	return 0;
+}
+
+extern "C" void *h264_amd_engine_stream(struct h264_amd_engine *e)
+{
+	return e ? (void *)e->stream : NULL;
+}
+
+extern "C" int h264_amd_malloc(struct h264_amd_engine *e, size_t size,
+			       void **d_ptr)
+{
+	if (e == NULL || d_ptr == NULL)
+		return -EINVAL;
+	HIP_TRY(hipSetDevice(e->device));
+	/* slack so that 16-byte vector accesses at the tail stay in bounds */
+	HIP_TRY(hipMalloc(d_ptr, size + 64));
+	return 0;
+}
+
+extern "C" int h264_amd_free(struct h264_amd_engine *e, void *d_ptr)
+{
+	if (e == NULL)
+		return -EINVAL;
+	HIP_TRY(hipFree(d_ptr));
+	return 0;
+}
+
+extern "C" int h264_amd_upload(struct h264_amd_engine *e, void *d_dst,
+			       const void *src, size_t size)
+{
+	if (e == NULL)
+		return -EINVAL;
+	HIP_TRY(hipMemcpyAsync(d_dst, src, size, hipMemcpyHostToDevice, e->stream));
+	HIP_TRY(hipStreamSynchronize(e->stream));
+	return 0;
+}
+
+extern "C" int h264_amd_download(struct h264_amd_engine *e, void *dst,
+				 const void *d_src, size_t size)
+{
+	if (e == NULL)
+		return -EINVAL;
+	HIP_TRY(hipMemcpyAsync(dst, d_src, size, hipMemcpyDeviceToHost, e->stream));
+	HIP_TRY(hipStreamSynchronize(e->stream));
+	return 0;
+}
+
+extern "C" int h264_amd_memset(struct h264_amd_engine *e, void *d_dst, int value,
+			       size_t size)
+{
+	if (e == NULL)
+		return -EINVAL;
+	HIP_TRY(hipMemsetAsync(d_dst, value, size, e->stream));
+	return 0;
+}
+
+extern "C" int h264_amd_last_kernel_ms(struct h264_amd_engine *e,
+				       const char *family, float *ms)
+{
+	static const char *const names[FAM_COUNT] = {"scan", "decode", "write",
+						     "synth"};
+	if (e == NULL || family == NULL || ms == NULL)
+		return -EINVAL;
+	for (int f = 0; f < FAM_COUNT; f++) {
+		if (strcmp(family, names[f]) != 0)
+			continue;
+		if (!e->timed[f])
+			return -ENOENT;
+		HIP_TRY(hipEventSynchronize(e->ev[f][1]));
+		HIP_TRY(hipEventElapsedTime(ms, e->ev[f][0], e->ev[f][1]));
+		return 0;
+	}
+	return -EINVAL;
+}
+
+/* ---- parameter-set snapshots ---------------------------------------------- */
+
+extern "C" int h264_amd_params_new(struct h264_amd_params **ret)
+{
+	if (ret == NULL)
+		return -EINVAL;
+	h264_amd_params *p = new (std::nothrow) h264_amd_params();
+	if (p == NULL)
+		return -ENOMEM;
+	*ret = p;
+	return h264_amd_params_reset(p);
+}
+
+extern "C" int h264_amd_params_destroy(struct h264_amd_params *p)
+{
+	delete p;
+	return 0;
+}
+
+extern "C" int h264_amd_params_reset(struct h264_amd_params *p)
+{
+	if (p == NULL)
+		return -EINVAL;
+	p->sps_full.clear();
+	p->pps_full.clear();
+	p->sps.clear();
+	p->pps.clear();
+	p->epochs.clear();
+	dev_epoch e0;
+	memset(&e0, 0xff, sizeof(e0)); /* every id: DEV_NO_VERSION */
+	p->epochs.push_back(e0);
+	p->serial++;
+	p->max_width_mbs = 1;
+	p->max_pic_mbs = 1;
+	return 0;
+}
+
+extern "C" int h264_amd_params_epoch(const struct h264_amd_params *p)
+{
+	return p ? (int)p->epochs.size() - 1 : -EINVAL;
+}
+
+extern "C" int h264_amd_params_put_sps(struct h264_amd_params *p,
+				       const struct h264_sps *sps)
+{
+	if (p == NULL || sps == NULL || sps->seq_parameter_set_id >= 32)
+		return -EINVAL;
+	const dev_epoch &cur = p->epochs.back();
+	uint16_t v = cur.sps_ver[sps->seq_parameter_set_id];
+	if (v != DEV_NO_VERSION && memcmp(&p->sps_full[v], sps, sizeof(*sps)) == 0)
+		return h264_amd_params_epoch(p);
+	if (p->sps.size() >= DEV_NO_VERSION)
+		return -ENOSPC;
+	dev_sps d;
+	memset(&d, 0, sizeof(d));
+	d.chroma_format_idc = (uint8_t)sps->chroma_format_idc;
+	d.separate_colour_plane_flag = (uint8_t)sps->separate_colour_plane_flag;
+	d.bit_depth_luma = (uint8_t)(8 + sps->bit_depth_luma_minus8);
+	d.bit_depth_chroma = (uint8_t)(8 + sps->bit_depth_chroma_minus8);
+	d.log2_max_frame_num = (uint8_t)(4 + sps->log2_max_frame_num_minus4);
+	d.pic_order_cnt_type = (uint8_t)sps->pic_order_cnt_type;
+	d.log2_max_pic_order_cnt_lsb =
+		(uint8_t)(4 + sps->log2_max_pic_order_cnt_lsb_minus4);
+	d.delta_pic_order_always_zero_flag =
+		(uint8_t)sps->delta_pic_order_always_zero_flag;
+	d.frame_mbs_only_flag = (uint8_t)sps->frame_mbs_only_flag;
+	d.mb_adaptive_frame_field_flag = (uint8_t)sps->mb_adaptive_frame_field_flag;
+	d.direct_8x8_inference_flag = (uint8_t)sps->direct_8x8_inference_flag;
+	d.pic_width_in_mbs = sps->pic_width_in_mbs_minus1 + 1;
+	d.pic_height_in_map_units = sps->pic_height_in_map_units_minus1 + 1;
+	p->sps_full.push_back(*sps);
+	p->sps.push_back(d);
+	dev_epoch ne = cur;
+	ne.sps_ver[sps->seq_parameter_set_id] = (uint16_t)(p->sps.size() - 1);
+	p->epochs.push_back(ne);
+	p->serial++;
+	if (d.pic_width_in_mbs > p->max_width_mbs)
+		p->max_width_mbs = d.pic_width_in_mbs;
+	uint64_t mbs = (uint64_t)d.pic_width_in_mbs * d.pic_height_in_map_units *
+		       (2 - (sps->frame_mbs_only_flag ? 1 : 0));
+	if (mbs > p->max_pic_mbs && mbs < 0x7fffffffu)
+		p->max_pic_mbs = (uint32_t)mbs;
+	return h264_amd_params_epoch(p);
+}
+
+extern "C" int h264_amd_params_put_pps(struct h264_amd_params *p,
+				       const struct h264_pps *pps)
+{
+	if (p == NULL || pps == NULL || pps->pic_parameter_set_id >= 256)
+		return -EINVAL;
+	const dev_epoch &cur = p->epochs.back();
+	uint16_t v = cur.pps_ver[pps->pic_parameter_set_id];
+	if (v != DEV_NO_VERSION && memcmp(&p->pps_full[v], pps, sizeof(*pps)) == 0)
+		return h264_amd_params_epoch(p);
+	if (p->pps.size() >= DEV_NO_VERSION)
+		return -ENOSPC;
+	dev_pps d;
+	memset(&d, 0, sizeof(d));
+	d.seq_parameter_set_id = (uint8_t)(pps->seq_parameter_set_id < 255
+						   ? pps->seq_parameter_set_id
+						   : 255);
+	d.entropy_coding_mode_flag = (uint8_t)pps->entropy_coding_mode_flag;
+	d.bottom_field_pic_order_in_frame_present_flag =
+		(uint8_t)pps->bottom_field_pic_order_in_frame_present_flag;
+	d.num_slice_groups_minus1 = (uint8_t)pps->num_slice_groups_minus1;
+	d.slice_group_map_type = (uint8_t)pps->slice_group_map_type;
+	d.weighted_pred_flag = (uint8_t)pps->weighted_pred_flag;
+	d.weighted_bipred_idc = (uint8_t)pps->weighted_bipred_idc;
+	d.deblocking_filter_control_present_flag =
+		(uint8_t)pps->deblocking_filter_control_present_flag;
+	d.redundant_pic_cnt_present_flag =
+		(uint8_t)pps->redundant_pic_cnt_present_flag;
+	d.transform_8x8_mode_flag = (uint8_t)pps->transform_8x8_mode_flag;
+	d.constrained_intra_pred_flag = (uint8_t)pps->constrained_intra_pred_flag;
+	d.pic_init_qp_minus26 = pps->pic_init_qp_minus26;
+	d.pic_init_qs_minus26 = pps->pic_init_qs_minus26;
+	d.num_ref_idx_l0_default_active_minus1 =
+		pps->num_ref_idx_l0_default_active_minus1;
+	d.num_ref_idx_l1_default_active_minus1 =
+		pps->num_ref_idx_l1_default_active_minus1;
+	d.slice_group_change_rate_minus1 = pps->slice_group_change_rate_minus1;
+	p->pps_full.push_back(*pps);
+	p->pps.push_back(d);
+	dev_epoch ne = cur;
+	ne.pps_ver[pps->pic_parameter_set_id] = (uint16_t)(p->pps.size() - 1);
+	p->epochs.push_back(ne);
+	p->serial++;
+	return h264_amd_params_epoch(p);
+}
+
+template <typename T>
+static int upload_vec(T **d, size_t *cap, const std::vector<T> &v,
+		      hipStream_t s)
+{
+	size_t n = v.size() ? v.size() : 1;
+	if (n > *cap) {
+		hipFree(*d);
+		*d = NULL;
+		size_t nc = n * 2;
+		HIP_TRY(hipMalloc((void **)d, nc * sizeof(T)));
+		*cap = nc;
+	}
+	if (v.size())
+		HIP_TRY(hipMemcpyAsync(*d, v.data(), v.size() * sizeof(T),
+				       hipMemcpyHostToDevice, s));
+	return 0;
+}
+
+static int sync_params(h264_amd_engine *e, const h264_amd_params *p)
+{
+	if (e->params_src == p && e->params_serial == p->serial)
+		return 0;
+	/* the source vectors may be reallocated by the caller afterwards */
+	int r;
+	if ((r = upload_vec(&e->d_sps, &e->cap_sps, p->sps, e->stream)) < 0)
+		return r;
+	if ((r = upload_vec(&e->d_pps, &e->cap_pps, p->pps, e->stream)) < 0)
+		return r;
+	if ((r = upload_vec(&e->d_epochs, &e->cap_epochs, p->epochs, e->stream)) < 0)
+		return r;
+	HIP_TRY(hipStreamSynchronize(e->stream));
+	e->params_src = p;
+	e->params_serial = p->serial;
+	return 0;
+}
+
+/* ---- slice decode ------------------------------------------------------------ */
+
+extern "C" int h264_amd_decode_slices(struct h264_amd_engine *e,
+				      const struct h264_amd_params *params,
+				      const struct h264_amd_decode_args *args)
+{
+	if (e == NULL || params == NULL || args == NULL)
+		return -EINVAL;
+	if (args->n == 0)
+		return 0;
+	if (args->d_buf == NULL || args->d_descs == NULL || args->d_results == NULL)
+		return -EINVAL;
+	uint32_t stride = args->mb_stride;
+	if (args->d_mb_out != NULL) {
+		if (args->tier == H264_AMD_TIER_T0 && stride < 4)
+			return -EINVAL;
+		if (args->tier == H264_AMD_TIER_T1 && stride < 64)
+			return -EINVAL;
+		if (args->tier == H264_AMD_TIER_T2 &&
+		    (stride < h264_amd_t2_stride(3) || (stride & 15)))
+			return -EINVAL;
+		if (args->tier > H264_AMD_TIER_T2)
+			return -EINVAL;
+	}
+	HIP_TRY(hipSetDevice(e->device));
+	int r = sync_params(e, params);
+	if (r < 0)
+		return r;
+
+	sd_args a;
+	memset(&a, 0, sizeof(a));
+	a.buf = args->d_buf;
+	a.descs = args->d_descs;
+	a.n = args->n;
+	a.spsv = e->d_sps;
+	a.ppsv = e->d_pps;
+	a.epochs = e->d_epochs;
+	a.n_sps = (uint32_t)params->sps.size();
+	a.n_pps = (uint32_t)params->pps.size();
+	a.n_epochs = (uint32_t)params->epochs.size();
+	a.vlc = e->d_vlc;
+	a.reader_flags = args->reader_flags;
+	a.tier = args->d_mb_out ? args->tier : (uint32_t)H264_AMD_TIER_NONE;
+	a.mb_capacity = args->mb_capacity;
+	a.mb_stride = stride;
+	a.results = args->d_results;
+	a.headers = args->d_headers;
+	a.mb_out = args->d_mb_out;
+	a.row_pitch = params->max_width_mbs;
+
+	size_t lds = SD_ROW_OFF + 16u * (size_t)a.row_pitch;
+	if (lds > 160u * 1024u)
+		return -E2BIG;
+	if (lds > 48u * 1024u)
+		HIP_TRY(hipFuncSetAttribute(
+			(const void *)h264_amd_k_decode_slices,
+			hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+	HIP_TRY(hipEventRecord(e->ev[FAM_DECODE][0], e->stream));
+	hipLaunchKernelGGL(h264_amd_k_decode_slices, dim3(a.n), dim3(64), lds,
+			   e->stream, a);
+	HIP_TRY(hipGetLastError());
+	HIP_TRY(hipEventRecord(e->ev[FAM_DECODE][1], e->stream));
+	e->timed[FAM_DECODE] = true;
+	return 0;
+}
+
+#include "engine_more.inc"

@@ -1,0 +1,72 @@
+/**
+ * dev_params.h -- device-side view of parameter sets (host + device).
+ *
+ * A slice header can only be parsed with the SPS/PPS that were active at the
+ * slice's position in the stream (ref src/h264_syntax.h:1256-1258: the header
+ * reads pic_parameter_set_id and calls h264_ctx_set_active_pps, which then
+ * activates the SPS the PPS names, src/h264_ctx.c:366-386).  The host keeps
+ * every parameter-set VERSION it has seen in compact form and, per epoch, the
+ * version each of the 256 PPS ids / 32 SPS ids pointed to; the kernels do the
+ * two look-ups themselves.
+ */
+#ifndef H264_AMD_DEV_PARAMS_H
+#define H264_AMD_DEV_PARAMS_H
+
+#include <stdint.h>
+
+#define DEV_NO_VERSION 0xffffu
+
+/* fields of struct h264_sps the slice kernels read (32 bytes) */
+struct dev_sps {
+	uint8_t chroma_format_idc;
+	uint8_t separate_colour_plane_flag;
+	uint8_t bit_depth_luma; /* 8..14 */
+	uint8_t bit_depth_chroma;
+	uint8_t log2_max_frame_num; /* 4..16 */
+	uint8_t pic_order_cnt_type;
+	uint8_t log2_max_pic_order_cnt_lsb;
+	uint8_t delta_pic_order_always_zero_flag;
+	uint8_t frame_mbs_only_flag;
+	uint8_t mb_adaptive_frame_field_flag;
+	uint8_t direct_8x8_inference_flag;
+	uint8_t pad0;
+	uint32_t pic_width_in_mbs;
+	uint32_t pic_height_in_map_units;
+	uint32_t pad1[3];
+};
+
+/* fields of struct h264_pps the slice kernels read (32 bytes) */
+struct dev_pps {
+	uint8_t seq_parameter_set_id;
+	uint8_t entropy_coding_mode_flag;
+	uint8_t bottom_field_pic_order_in_frame_present_flag;
+	uint8_t num_slice_groups_minus1;
+	uint8_t slice_group_map_type;
+	uint8_t weighted_pred_flag;
+	uint8_t weighted_bipred_idc;
+	uint8_t deblocking_filter_control_present_flag;
+	uint8_t redundant_pic_cnt_present_flag;
+	uint8_t transform_8x8_mode_flag;
+	uint8_t constrained_intra_pred_flag;
+	uint8_t pad0;
+	int32_t pic_init_qp_minus26;
+	int32_t pic_init_qs_minus26;
+	uint32_t num_ref_idx_l0_default_active_minus1;
+	uint32_t num_ref_idx_l1_default_active_minus1;
+	uint32_t slice_group_change_rate_minus1;
+};
+
+/* which version every id names during one epoch */
+struct dev_epoch {
+	uint16_t pps_ver[256];
+	uint16_t sps_ver[32];
+};
+
+/* lane-resident prefix-code tables: [row][lane], rows 0..21 described in
+ * vlc_lanes.hip.h, row 22 = coded_block_pattern mapping (lane = codeNum) */
+#define DEV_VLC_TABLES 23
+struct dev_vlc_tables {
+	uint32_t e[DEV_VLC_TABLES][64];
+};
+
+#endif /* H264_AMD_DEV_PARAMS_H */

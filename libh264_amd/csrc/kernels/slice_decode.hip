@@ -1,0 +1,1244 @@
+/**
+ * slice_decode.hip -- one slice NAL unit per wavefront: slice header +
+ * CAVLC slice_data, hand written for gfx950 (MI355X).
+ *
+ * Replaces, for nal_unit_type 1 and 5, what the reference does per NAL in
+ *   _h264_read_nalu / slice_layer / slice_header   src/h264_syntax.h:1239-1604
+ *   _h264_read_slice_data(_internal)               src/h264_syntax_slice_data.h:701-811
+ *   macroblock_layer / mb_pred / sub_mb_pred       src/h264_syntax_slice_data.h:422-696
+ *   residual / residual_luma / residual_block      src/h264_syntax_slice_data.h:103-419
+ *   mb_type, sub_mb_type, cbp, coeff_token & co    src/h264_slice_data.c:839-1416
+ *   neighbour derivation (non-MBAFF)               src/h264_macroblock.c:84-104,306-433
+ * with the reference's observable results (slice header struct, rawdata extent,
+ * per-macroblock syntax, nz_coeff bookkeeping incl. its quirks, error points).
+ *
+ * Execution model: grid = number of slices, block = ONE wave (64 lanes).  The
+ * parse state is wave-uniform and lives in SGPRs (see wave_bits.hip.h); the
+ * lanes cooperate for
+ *   - ingesting/de-escaping the bitstream (coalesced loads, ballot compaction),
+ *   - matching prefix codes (one candidate code word per lane, vlc_lanes.hip.h),
+ *   - scattering run/level pairs of a 4x4 block into the record (lane i owns
+ *     coefficient i; position = zerosLeft_i + TotalCoeff - 1 - i),
+ *   - the nz_coeff neighbour context (lane = comp*16 + blkIdx, v_readlane),
+ *   - staging the macroblock record in LDS and writing it out with 16-byte
+ *     stores, plus the order-independent checksum over it.
+ * No MFMA: this is integer/bit work.  LDS per wave: 1 KiB RBSP ring + 4 KiB
+ * record staging + 16 B per macroblock column of top-row nz context.
+ *
+ * Out of scope (status H264_AMD_E_UNSUPPORTED): MBAFF frames and slice groups.
+ */
+#include <hip/hip_runtime.h>
+#include <errno.h>
+#include <stddef.h>
+#include <stdint.h>
+
+#include <h264_amd.h>
+
+#include "dev_params.h"
+#include "vlc_lanes.hip.h"
+#include "wave_bits.hip.h"
+
+#define SD_RING_OFF 0u
+#define SD_STATE_OFF 1024u
+#define SD_STAGE_OFF (1024u + WB_STATE_BYTES)
+#define SD_STAGE_BYTES 4096u
+#define SD_ROW_OFF (SD_STAGE_OFF + SD_STAGE_BYTES)
+
+/* private enums of the reference (src/h264_macroblock.h:36-60) */
+enum { PM_I4x4, PM_I8x8, PM_I16x16, PM_L0, PM_L1, PM_BI, PM_DIRECT };
+
+struct SliceState {
+	/* parameter sets */
+	uint32_t cat, W, bdl, bdc, pcm_chroma;
+	uint32_t t8x8_mode, direct8x8, entropy, unsupported;
+	/* header */
+	uint32_t slice_type, first_mb, nref0, nref1, field_pic;
+	int32_t slice_qp;
+	uint32_t nal_ref_idc, nal_unit_type;
+	uint32_t hdr_len_bits, rawdata_off, rawdata_len, partial, partialbits;
+};
+
+__device__ __forceinline__ void lds_w32(uint8_t *p, uint32_t off, uint32_t v,
+					uint32_t lane)
+{
+	if (lane == 0)
+		*reinterpret_cast<uint32_t *>(p + off) = v;
+}
+
+__device__ __forceinline__ void lds_w16(uint8_t *p, uint32_t off, uint32_t v,
+					uint32_t lane)
+{
+	if (lane == 0)
+		*reinterpret_cast<uint16_t *>(p + off) = (uint16_t)v;
+}
+
+__device__ __forceinline__ void lds_w8(uint8_t *p, uint32_t off, uint32_t v,
+				       uint32_t lane)
+{
+	if (lane == 0)
+		p[off] = (uint8_t)v;
+}
+
+#define HOFF(f) ((uint32_t)offsetof(struct h264_slice_header, f))
+#define HP(f, v) lds_w32(stage, HOFF(f), (uint32_t)(v), lane)
+
+#define RD_UE(var)                                                             \
+	do {                                                                   \
+		var = wb_ue(wb, lane, ok);                                     \
+		if (!ok)                                                       \
+			return -EIO;                                           \
+	} while (0)
+#define RD_SE(var)                                                             \
+	do {                                                                   \
+		var = wb_se(wb, lane, ok);                                     \
+		if (!ok)                                                       \
+			return -EIO;                                           \
+	} while (0)
+
+/* Load a small POD from global memory so that every field is wave-uniform
+ * (SGPR): the compiler cannot prove a vector load from a uniform address
+ * uniform by itself, and everything derived from the parameter sets steers
+ * scalar control flow. */
+template <typename T>
+__device__ __forceinline__ void sd_load_uniform(T *dst, const T *src)
+{
+	static_assert(sizeof(T) % 4 == 0, "dword multiple");
+	const uint32_t *s = reinterpret_cast<const uint32_t *>(src);
+	uint32_t *d = reinterpret_cast<uint32_t *>(dst);
+#pragma unroll
+	for (uint32_t i = 0; i < sizeof(T) / 4; i++)
+		d[i] = wb_uniform(s[i]);
+}
+
+__device__ __forceinline__ uint32_t sd_t2_stride(uint32_t cat)
+{
+	return 256u + 2u * (cat == 0 ? 256u : cat == 1 ? 384u : cat == 2 ? 512u : 768u);
+}
+
+/* Calculate log2 rounded up, 0 -> 0 (ref src/h264_priv.h:185-193) */
+__device__ __forceinline__ uint32_t sd_intlog2(uint32_t x)
+{
+	uint32_t r = x ? 32u - (uint32_t)__builtin_clz(x) : 0u;
+	if (r > 0 && x == (1u << (r - 1u)))
+		r--;
+	return r;
+}
+
+/* ---- slice header (ref src/h264_syntax.h:1014-1387) --------------------- */
+
+__device__ __forceinline__ int sd_rplm_items(WaveBits &wb, uint32_t lane,
+					     uint8_t *stage, uint32_t off)
+{
+	bool ok = true;
+	uint32_t i = 0, val;
+	do {
+		if (i >= 32)
+			return -EIO;
+		wb_sync(wb, lane);
+		RD_UE(val);
+		lds_w32(stage, off + 8 * i, val, lane);
+		if (val == 0 || val == 1 || val == 2 || val == 4 || val == 5) {
+			uint32_t v;
+			RD_UE(v);
+			lds_w32(stage, off + 8 * i + 4, v, lane);
+		}
+		i++;
+	} while (val != 3);
+	return 0;
+}
+
+__device__ __forceinline__ int sd_pwt_list(WaveBits &wb, uint32_t lane,
+					   uint8_t *stage, uint32_t off,
+					   uint32_t count, uint32_t cat)
+{
+	bool ok = true;
+	for (uint32_t i = 0; i < count; i++) {
+		uint32_t o = off + 32 * i; /* sizeof(struct h264_pwt_item) */
+		int32_t v;
+		wb_sync(wb, lane);
+		uint32_t f = wb_u1(wb, lane);
+		lds_w32(stage, o, f, lane);
+		if (f) {
+			RD_SE(v);
+			lds_w32(stage, o + 4, (uint32_t)v, lane);
+			RD_SE(v);
+			lds_w32(stage, o + 8, (uint32_t)v, lane);
+		}
+		if (cat != 0) {
+			f = wb_u1(wb, lane);
+			lds_w32(stage, o + 12, f, lane);
+			if (f) {
+				/* weight[0], offset[0], weight[1], offset[1] */
+				RD_SE(v);
+				lds_w32(stage, o + 16, (uint32_t)v, lane);
+				RD_SE(v);
+				lds_w32(stage, o + 24, (uint32_t)v, lane);
+				RD_SE(v);
+				lds_w32(stage, o + 20, (uint32_t)v, lane);
+				RD_SE(v);
+				lds_w32(stage, o + 28, (uint32_t)v, lane);
+			}
+		}
+	}
+	return 0;
+}
+
+__device__ __forceinline__ int
+sd_slice_header(WaveBits &wb, uint32_t lane, uint8_t *stage, SliceState &S,
+		const dev_sps *spsv, const dev_pps *ppsv, const dev_epoch *ep,
+		uint32_t n_sps, uint32_t n_pps)
+{
+	bool ok = true;
+	uint32_t v, type, raw_type, pps_id;
+	int32_t sv;
+
+	RD_UE(v);
+	HP(first_mb_in_slice, v);
+	S.first_mb = v;
+	RD_UE(raw_type);
+	HP(slice_type, raw_type);
+	type = raw_type % 5u;
+	RD_UE(pps_id);
+	HP(pic_parameter_set_id, pps_id);
+
+	/* h264_ctx_set_active_pps -> set_active_sps (src/h264_ctx.c:366-386) */
+	if (pps_id >= 256)
+		return -EINVAL;
+	uint32_t pv = wb_uniform(ep->pps_ver[pps_id]);
+	if (pv == DEV_NO_VERSION || pv >= n_pps)
+		return -EINVAL;
+	dev_pps pps;
+	sd_load_uniform(&pps, ppsv + pv);
+	if (pps.seq_parameter_set_id >= 32)
+		return -EINVAL;
+	uint32_t sver = wb_uniform(ep->sps_ver[pps.seq_parameter_set_id]);
+	if (sver == DEV_NO_VERSION || sver >= n_sps)
+		return -EINVAL;
+	dev_sps sps;
+	sd_load_uniform(&sps, spsv + sver);
+
+	S.cat = sps.separate_colour_plane_flag ? 0u : sps.chroma_format_idc;
+	S.W = sps.pic_width_in_mbs;
+	S.bdl = sps.bit_depth_luma;
+	S.bdc = sps.bit_depth_chroma;
+	S.pcm_chroma = S.cat == 0 ? 0u : S.cat == 1 ? 64u : S.cat == 2 ? 128u : 256u;
+	S.t8x8_mode = pps.transform_8x8_mode_flag;
+	S.direct8x8 = sps.direct_8x8_inference_flag;
+	S.entropy = pps.entropy_coding_mode_flag;
+	S.slice_type = type;
+
+	uint32_t nref0 = pps.num_ref_idx_l0_default_active_minus1;
+	uint32_t nref1 = pps.num_ref_idx_l1_default_active_minus1;
+	uint32_t field_pic = 0;
+
+	if (sps.separate_colour_plane_flag) {
+		v = wb_u(wb, lane, 2);
+		HP(colour_plane_id, v);
+	}
+	v = wb_u(wb, lane, sps.log2_max_frame_num);
+	HP(frame_num, v);
+	if (!sps.frame_mbs_only_flag) {
+		field_pic = wb_u1(wb, lane);
+		HP(field_pic_flag, field_pic);
+		if (field_pic) {
+			v = wb_u1(wb, lane);
+			HP(bottom_field_flag, v);
+		}
+	}
+	if (S.nal_unit_type == 5) {
+		RD_UE(v);
+		HP(idr_pic_id, v);
+	}
+	wb_sync(wb, lane);
+	if (sps.pic_order_cnt_type == 0) {
+		v = wb_u(wb, lane, sps.log2_max_pic_order_cnt_lsb);
+		HP(pic_order_cnt_lsb, v);
+		if (pps.bottom_field_pic_order_in_frame_present_flag && !field_pic) {
+			RD_SE(sv);
+			HP(delta_pic_order_cnt_bottom, sv);
+		}
+	}
+	if (sps.pic_order_cnt_type == 1 && !sps.delta_pic_order_always_zero_flag) {
+		RD_SE(sv);
+		HP(delta_pic_order_cnt[0], sv);
+		if (pps.bottom_field_pic_order_in_frame_present_flag && !field_pic) {
+			RD_SE(sv);
+			HP(delta_pic_order_cnt[1], sv);
+		}
+	}
+	if (pps.redundant_pic_cnt_present_flag) {
+		RD_UE(v);
+		HP(redundant_pic_cnt, v);
+	}
+	if (type == H264_SLICE_TYPE_B) {
+		v = wb_u1(wb, lane);
+		HP(direct_spatial_mv_pred_flag, v);
+	}
+	wb_sync(wb, lane);
+	if (type == H264_SLICE_TYPE_P || type == H264_SLICE_TYPE_SP ||
+	    type == H264_SLICE_TYPE_B) {
+		v = wb_u1(wb, lane);
+		HP(num_ref_idx_active_override_flag, v);
+		if (v) {
+			RD_UE(nref0);
+			if (type == H264_SLICE_TYPE_B)
+				RD_UE(nref1);
+		}
+	}
+	HP(num_ref_idx_l0_active_minus1, nref0);
+	HP(num_ref_idx_l1_active_minus1, nref1);
+
+	/* ref_pic_list_modification */
+	if (type != H264_SLICE_TYPE_I && type != H264_SLICE_TYPE_SI) {
+		v = wb_u1(wb, lane);
+		HP(rplm.ref_pic_list_modification_flag_l0, v);
+		if (v) {
+			int r = sd_rplm_items(wb, lane, stage, HOFF(rplm.pic_num_l0));
+			if (r)
+				return r;
+		}
+	}
+	if (type == H264_SLICE_TYPE_B) {
+		v = wb_u1(wb, lane);
+		HP(rplm.ref_pic_list_modification_flag_l1, v);
+		if (v) {
+			int r = sd_rplm_items(wb, lane, stage, HOFF(rplm.pic_num_l1));
+			if (r)
+				return r;
+		}
+	}
+	wb_sync(wb, lane);
+	/* pred_weight_table */
+	if ((pps.weighted_pred_flag &&
+	     (type == H264_SLICE_TYPE_P || type == H264_SLICE_TYPE_SP)) ||
+	    (pps.weighted_bipred_idc == 1 && type == H264_SLICE_TYPE_B)) {
+		uint32_t pcat = sps.separate_colour_plane_flag
+					? 0u
+					: sps.chroma_format_idc;
+		RD_UE(v);
+		HP(pwt.luma_log2_weight_denom, v);
+		if (pcat != 0) {
+			RD_UE(v);
+			HP(pwt.chroma_log2_weight_denom, v);
+		}
+		if (nref0 > 32)
+			return -EIO;
+		int r = sd_pwt_list(wb, lane, stage, HOFF(pwt.l0), nref0 + 1, pcat);
+		if (r)
+			return r;
+		if (type == H264_SLICE_TYPE_B) {
+			if (nref1 > 32)
+				return -EIO;
+			r = sd_pwt_list(wb, lane, stage, HOFF(pwt.l1), nref1 + 1,
+					pcat);
+			if (r)
+				return r;
+		}
+	}
+	wb_sync(wb, lane);
+	/* dec_ref_pic_marking */
+	if (S.nal_ref_idc != 0) {
+		if (S.nal_unit_type == 5) {
+			v = wb_u1(wb, lane);
+			HP(drpm.no_output_of_prior_pics_flag, v);
+			v = wb_u1(wb, lane);
+			HP(drpm.long_term_reference_flag, v);
+		} else {
+			v = wb_u1(wb, lane);
+			HP(drpm.adaptive_ref_pic_marking_mode_flag, v);
+			if (v) {
+				uint32_t i = 0, op;
+				do {
+					uint32_t o = HOFF(drpm.mm) + 20 * i;
+					if (i >= 64)
+						return -EIO;
+					wb_sync(wb, lane);
+					RD_UE(op);
+					lds_w32(stage, o, op, lane);
+					if (op == 1 || op == 3) {
+						RD_UE(v);
+						lds_w32(stage, o + 4, v, lane);
+					}
+					if (op == 2) {
+						RD_UE(v);
+						lds_w32(stage, o + 8, v, lane);
+					}
+					if (op == 3 || op == 6) {
+						RD_UE(v);
+						lds_w32(stage, o + 12, v, lane);
+					}
+					if (op == 4) {
+						RD_UE(v);
+						lds_w32(stage, o + 16, v, lane);
+					}
+					i++;
+				} while (op != 0);
+			}
+		}
+	}
+	wb_sync(wb, lane);
+	if (pps.entropy_coding_mode_flag && type != H264_SLICE_TYPE_I &&
+	    type != H264_SLICE_TYPE_SI) {
+		RD_UE(v);
+		HP(cabac_init_idc, v);
+	}
+	RD_SE(sv);
+	HP(slice_qp_delta, sv);
+	S.slice_qp = pps.pic_init_qp_minus26 + 26 + sv;
+	if (type == H264_SLICE_TYPE_SP || type == H264_SLICE_TYPE_SI) {
+		if (type == H264_SLICE_TYPE_SP) {
+			v = wb_u1(wb, lane);
+			HP(sp_for_switch_flag, v);
+		}
+		RD_SE(sv);
+		HP(slice_qs_delta, sv);
+	}
+	if (pps.deblocking_filter_control_present_flag) {
+		RD_UE(v);
+		HP(disable_deblocking_filter_idc, v);
+		if (v != 1) {
+			RD_SE(sv);
+			HP(slice_alpha_c0_offset_div2, sv);
+			RD_SE(sv);
+			HP(slice_beta_offset_div2, sv);
+		}
+	}
+	if (pps.num_slice_groups_minus1 > 0 && pps.slice_group_map_type >= 3 &&
+	    pps.slice_group_map_type <= 5) {
+		uint32_t units = sps.pic_width_in_mbs * sps.pic_height_in_map_units;
+		uint32_t n = sd_intlog2(
+			units / (pps.slice_group_change_rate_minus1 + 1u) + 1u);
+		v = n ? wb_u(wb, lane, n) : 0u;
+		HP(slice_group_change_cycle, v);
+	}
+	S.nref0 = nref0;
+	S.nref1 = nref1;
+	S.field_pic = field_pic;
+	S.unsupported = (sps.mb_adaptive_frame_field_flag && !field_pic) ||
+			pps.num_slice_groups_minus1 > 0;
+	return 0;
+}
+
+/* ---- macroblock bookkeeping ---------------------------------------------- */
+
+struct MbCtx {
+	/* per lane: nz_coeff of the current / left / above macroblock, lane =
+	 * comp * 16 + blkIdx (above: only its bottom row is populated) */
+	uint32_t cur, left, top;
+	int row_slot; /* per lane: byte of the row context this lane owns */
+	/* uniform */
+	uint32_t availA, availB;
+};
+
+/* z-order index of the 4x4 luma block at (x, y), 6.4.13.1 */
+__device__ __forceinline__ uint32_t blk_at(uint32_t x, uint32_t y)
+{
+	return (x & 1u) | ((y & 1u) << 1) | ((x >> 1) << 2) | ((y >> 1) << 3);
+}
+
+/* nC of 9.2.1 as the reference computes it (src/h264_slice_data.c:1319-1334) */
+__device__ __forceinline__ uint32_t sd_nc(const MbCtx &m, uint32_t comp,
+					  uint32_t blk, uint32_t chroma,
+					  uint32_t cat)
+{
+	uint32_t x, y, lA, lB, w4, h4;
+	if (chroma) {
+		x = blk & 1u;
+		y = blk >> 1;
+		w4 = 2;
+		h4 = cat == 1 ? 2u : 4u;
+		lA = x ? 2u * y + x - 1u : 2u * y + w4 - 1u;
+		lB = y ? 2u * (y - 1u) + x : 2u * (h4 - 1u) + x;
+	} else {
+		x = (blk & 1u) | ((blk >> 1) & 2u);
+		y = ((blk >> 1) & 1u) | ((blk >> 2) & 2u);
+		lA = blk_at(x ? x - 1u : 3u, y);
+		lB = blk_at(x, y ? y - 1u : 3u);
+	}
+	lA += 16u * comp;
+	lB += 16u * comp;
+	uint32_t availA = x ? 1u : m.availA, availB = y ? 1u : m.availB;
+	uint32_t nA = (uint32_t)__builtin_amdgcn_readlane(
+		(int)(x ? m.cur : m.left), (int)lA);
+	uint32_t nB = (uint32_t)__builtin_amdgcn_readlane(
+		(int)(y ? m.cur : m.top), (int)lB);
+	if (availA && availB)
+		return (nA + nB + 1u) >> 1;
+	if (availA)
+		return nA;
+	if (availB)
+		return nB;
+	return 0;
+}
+
+/* 9.2 residual_block (ref src/h264_syntax_slice_data.h:103-242).  The decoded
+ * levels go to stage[coef_off ...] (int16 units from the record start).
+ * Returns 0 or -EIO; tc_out = TotalCoeff. */
+__device__ __forceinline__ int sd_residual_block(WaveBits &wb, const VlcLanes &vt,
+						 uint32_t lane, uint8_t *stage,
+						 uint32_t nC, uint32_t chroma_dc,
+						 uint32_t maxnum, uint32_t coef_off,
+						 uint32_t &tc_out)
+{
+	uint32_t t1, tc;
+	if (!vlc_coeff_token(vt, wb, lane, nC, chroma_dc, t1, tc))
+		return -EIO;
+	tc_out = tc;
+	if (tc == 0)
+		return 0;
+	uint32_t lv = 0; /* per lane: level i */
+	uint32_t zl = 0; /* per lane: zerosLeft before run i */
+	uint32_t suffix_len = (tc > 10 && t1 < 3) ? 1u : 0u;
+	uint32_t i = 0;
+	if (t1) {
+		uint32_t signs = wb_u(wb, lane, t1);
+		for (; i < t1; i++) {
+			uint32_t neg = (signs >> (t1 - 1u - i)) & 1u;
+			lv = wb_setlane(lv, i, neg ? 0xffffu : 1u, lane);
+		}
+	}
+	for (; i < tc; i++) {
+		uint32_t bits = wb_peek(wb, lane);
+		if (bits < (1u << 6))
+			return -EIO; /* level_prefix > 25 */
+		uint32_t prefix = (uint32_t)__builtin_clz(bits);
+		wb_skip(wb, prefix + 1u);
+		uint32_t code = (prefix < 15u ? prefix : 15u) << suffix_len;
+		if (suffix_len > 0 || prefix >= 14) {
+			uint32_t size = (prefix == 14 && suffix_len == 0) ? 4u
+					: prefix >= 15		  ? prefix - 3u
+								  : suffix_len;
+			if (size)
+				code += wb_u(wb, lane, size);
+		}
+		if (prefix >= 15 && suffix_len == 0)
+			code += 15;
+		if (prefix >= 16)
+			code += (1u << (prefix - 3u)) - 4096u;
+		if (i == t1 && t1 < 3)
+			code += 2;
+		int32_t val = (code & 1u) ? (-(int32_t)code - 1) >> 1
+					  : (int32_t)((code + 2u) >> 1);
+		int32_t v16 = (int16_t)val; /* levelVal is int16_t in the ref */
+		lv = wb_setlane(lv, i, (uint32_t)v16 & 0xffffu, lane);
+		if (suffix_len == 0)
+			suffix_len = 1;
+		int32_t a = v16 < 0 ? -v16 : v16;
+		if (a > (3 << (suffix_len - 1u)) && suffix_len < 6)
+			suffix_len++;
+	}
+	uint32_t zeros_left = 0;
+	if (tc < maxnum) {
+		if (!vlc_total_zeros(vt, wb, lane, tc, maxnum, zeros_left))
+			return -EIO;
+	}
+	for (i = 0; i + 1 < tc && zeros_left > 0; i++) {
+		uint32_t run;
+		zl = wb_setlane(zl, i, zeros_left, lane);
+		if (!vlc_run_before(vt, wb, lane, zeros_left, run))
+			return -EIO;
+		if (run > zeros_left)
+			return -EIO;
+		zeros_left -= run;
+	}
+	zl = wb_setlane(zl, tc - 1u, zeros_left, lane);
+	/* lane i places coefficient i */
+	uint32_t pos = zl + tc - 1u - lane;
+	bool mine = lane < tc;
+	if (__ballot(mine && pos >= maxnum))
+		return -EIO; /* malformed: outside the block (Appendix C.5) */
+	if (mine)
+		*reinterpret_cast<uint16_t *>(stage + H264_AMD_T2_HEAD +
+					      2u * (coef_off + pos)) = (uint16_t)lv;
+	return 0;
+}
+
+/* checksum terms of the staged record; a_w/b_w hold the multipliers of this
+ * lane's 8 words for the CURRENT macroblock index (stepped by the caller) */
+__device__ __forceinline__ void sd_checksum(const uint4 q, uint32_t abase,
+					    uint32_t bbase, uint32_t &lo,
+					    uint32_t &hi)
+{
+	const uint32_t d[4] = {q.x, q.y, q.z, q.w};
+#pragma unroll
+	for (int k = 0; k < 4; k++) {
+		uint32_t w0 = d[k] & 0xffffu, w1 = d[k] >> 16;
+		uint32_t a0 = abase + (uint32_t)(2 * k) * 0x9E3779B1u;
+		uint32_t a1 = a0 + 0x9E3779B1u;
+		uint32_t b0 = bbase + (uint32_t)(2 * k) * 0xC2B2AE3Du;
+		uint32_t b1 = b0 + 0xC2B2AE3Du;
+		lo += w0 * a0 + w1 * a1;
+		hi += (w0 * (w0 + 1u)) * b0 + (w1 * (w1 + 1u)) * b1;
+	}
+}
+
+struct OutCtx {
+	uint32_t tier, mb_stride, rec_bytes; /* rec_bytes = T2 stride for cat */
+	uint8_t *mb_out; /* this slice's output area */
+	uint32_t t0acc; /* per lane: T0 word of macroblock (idx & 63) */
+	uint32_t lo, hi; /* per lane checksum partials */
+};
+
+/* Finish one macroblock whose record is staged in LDS. */
+__device__ __forceinline__ void sd_emit_staged(OutCtx &o, const uint8_t *stage,
+					       uint32_t mbidx, uint32_t lane)
+{
+	uint32_t word0 = *reinterpret_cast<const uint32_t *>(stage);
+	for (uint32_t part = 0; part * 1024u < o.rec_bytes; part++) {
+		uint32_t off = part * 1024u + 16u * lane;
+		if (off < o.rec_bytes) {
+			uint4 q = *reinterpret_cast<const uint4 *>(stage + off);
+			uint32_t idx = mbidx * 1024u + off / 2u;
+			sd_checksum(q, idx * 0x9E3779B1u + 0x85EBCA77u,
+				    idx * 0xC2B2AE3Du + 0x27D4EB2Fu, o.lo, o.hi);
+			if (o.tier == H264_AMD_TIER_T2)
+				*reinterpret_cast<uint4 *>(
+					o.mb_out + (size_t)mbidx * o.mb_stride + off) = q;
+		}
+	}
+	if (o.tier == H264_AMD_TIER_T1 && lane < 16)
+		*reinterpret_cast<uint32_t *>(o.mb_out + (size_t)mbidx * o.mb_stride +
+					      4u * lane) =
+			*reinterpret_cast<const uint32_t *>(stage + 4u * lane);
+	if (o.tier == H264_AMD_TIER_T0) {
+		o.t0acc = wb_setlane(o.t0acc, mbidx & 63u, word0, lane);
+		if ((mbidx & 63u) == 63u)
+			*reinterpret_cast<uint32_t *>(
+				o.mb_out + (size_t)(mbidx - 63u + lane) * o.mb_stride) =
+				o.t0acc;
+	}
+}
+
+/* A skipped macroblock: the record is word0 followed by zeros. */
+__device__ __forceinline__ void sd_emit_skipped(OutCtx &o, uint32_t word0,
+						uint32_t mbidx, uint32_t lane)
+{
+	if (lane == 0) {
+		uint32_t idx = mbidx * 1024u;
+		uint4 q = make_uint4(word0, 0, 0, 0);
+		sd_checksum(q, idx * 0x9E3779B1u + 0x85EBCA77u,
+			    idx * 0xC2B2AE3Du + 0x27D4EB2Fu, o.lo, o.hi);
+	}
+	if (o.tier == H264_AMD_TIER_T2) {
+		for (uint32_t off = 16u * lane; off < o.rec_bytes; off += 1024u) {
+			uint4 q = make_uint4(off == 0 ? word0 : 0u, 0, 0, 0);
+			*reinterpret_cast<uint4 *>(
+				o.mb_out + (size_t)mbidx * o.mb_stride + off) = q;
+		}
+	} else if (o.tier == H264_AMD_TIER_T1) {
+		if (lane < 16)
+			*reinterpret_cast<uint32_t *>(
+				o.mb_out + (size_t)mbidx * o.mb_stride + 4u * lane) =
+				lane == 0 ? word0 : 0u;
+	} else if (o.tier == H264_AMD_TIER_T0) {
+		o.t0acc = wb_setlane(o.t0acc, mbidx & 63u, word0, lane);
+		if ((mbidx & 63u) == 63u)
+			*reinterpret_cast<uint32_t *>(
+				o.mb_out + (size_t)(mbidx - 63u + lane) * o.mb_stride) =
+				o.t0acc;
+	}
+}
+
+/* advance the neighbour context to the next macroblock */
+__device__ __forceinline__ void sd_next_mb(MbCtx &m, uint8_t *row, uint32_t &mbx,
+					   uint32_t W)
+{
+	if (m.row_slot >= 0)
+		row[16u * mbx + (uint32_t)m.row_slot] = (uint8_t)m.cur;
+	m.left = m.cur;
+	m.cur = 0;
+	mbx++;
+	if (mbx == W)
+		mbx = 0;
+}
+
+/* ---- slice data (ref src/h264_syntax_slice_data.h:701-787) -------------- */
+__device__ __forceinline__ int
+sd_slice_data(WaveBits &wb, const VlcLanes &vt, uint32_t cbp_map, uint32_t lane,
+	      uint8_t *stage, uint8_t *row, const SliceState &S, OutCtx &o,
+	      uint32_t mb_capacity, uint32_t &mb_count)
+{
+	const uint32_t cat = S.cat, W = S.W;
+	const bool is_i = S.slice_type == H264_SLICE_TYPE_I ||
+			  S.slice_type == H264_SLICE_TYPE_SI;
+	const bool is_b = S.slice_type == H264_SLICE_TYPE_B;
+	const bool is_p = S.slice_type == H264_SLICE_TYPE_P ||
+			  S.slice_type == H264_SLICE_TYPE_SP;
+	const bool chroma12 = cat == 1 || cat == 2;
+	const uint32_t nchroma = cat == 1 ? 4u : 8u; /* 4x4 blocks per component */
+	bool ok = true;
+	MbCtx m;
+	m.cur = m.left = m.top = 0;
+	m.availA = m.availB = 0;
+	/* which byte of the per-column row context this lane saves: the bottom
+	 * row of 4x4 blocks of every component */
+	{
+		uint32_t comp = lane >> 4, b = lane & 15u;
+		int slot = -1;
+		if (lane < 48) {
+			if (comp == 0 || cat == 3)
+				slot = b == 10 ? 0 : b == 11 ? 1 : b == 14 ? 2 : b == 15 ? 3 : -1;
+			else if (cat == 1)
+				slot = b == 2 ? 0 : b == 3 ? 1 : -1;
+			else if (cat == 2)
+				slot = b == 6 ? 0 : b == 7 ? 1 : -1;
+			if (slot >= 0)
+				slot += 4 * (int)comp;
+		}
+		m.row_slot = slot;
+	}
+	uint32_t mbx = S.first_mb % W;
+	uint32_t mbidx = 0;
+	const uint32_t skip_word0 =
+		(is_b ? (uint32_t)H264_MB_TYPE_B_SKIP : (uint32_t)H264_MB_TYPE_P_SKIP) |
+		((uint32_t)H264_AMD_MB_SKIPPED << 16);
+
+	do {
+		wb_sync(wb, lane);
+		if (wb_overrun(wb))
+			return -EIO;
+		if (!is_i) {
+			uint32_t run;
+			RD_UE(run);
+			for (uint32_t r = 0; r < run; r++) {
+				if (mbidx >= mb_capacity)
+					return H264_AMD_E_MB_OVERFLOW;
+				sd_emit_skipped(o, skip_word0, mbidx, lane);
+				sd_next_mb(m, row, mbx, W);
+				mbidx++;
+				mb_count = mbidx;
+			}
+			if (wb_overrun(wb))
+				return -EIO;
+			if (run > 0 && !wb_more_rbsp_data(wb, lane))
+				break;
+		}
+		if (mbidx >= mb_capacity)
+			return H264_AMD_E_MB_OVERFLOW;
+
+		/* ---- new macroblock: neighbours, clean record ---- */
+		m.availA = (mbx != 0 && mbidx >= 1) ? 1u : 0u;
+		m.availB = mbidx >= W ? 1u : 0u;
+		m.top = 0;
+		if (m.availB && m.row_slot >= 0)
+			m.top = row[16u * mbx + (uint32_t)m.row_slot];
+		for (uint32_t off = 16u * lane; off < o.rec_bytes; off += 1024u)
+			*reinterpret_cast<uint4 *>(stage + off) = make_uint4(0, 0, 0, 0);
+
+		/* ---- mb_type (ref src/h264_slice_data.c:839-969) ---- */
+		uint32_t raw_type, t, mb_type = 0, nparts = 0;
+		uint32_t pm0 = PM_I4x4, pm1 = PM_I4x4;
+		uint32_t i16pred = 0, cbp_luma = 0, cbp_chroma = 0;
+		bool intra = is_i; /* decode t with the I-slice table */
+		RD_UE(raw_type);
+		t = raw_type;
+		if (S.slice_type == H264_SLICE_TYPE_SI) {
+			if (t == 0) {
+				mb_type = H264_MB_TYPE_SI;
+				nparts = 1;
+				pm0 = PM_I4x4;
+				intra = false;
+			} else {
+				t -= 1;
+			}
+		} else if (is_p) {
+			if (t <= 4) {
+				mb_type = H264_MB_TYPE_P_16x16 + t;
+				nparts = t == 0 ? 1u : t <= 2 ? 2u : 4u;
+				pm0 = pm1 = nparts == 4 ? PM_I4x4 : PM_L0;
+			} else {
+				t -= 5;
+				intra = true;
+			}
+		} else if (is_b) {
+			if (t == 0) {
+				mb_type = H264_MB_TYPE_B_Direct_16x16;
+				nparts = 1;
+				pm0 = PM_DIRECT;
+			} else if (t <= 3) {
+				mb_type = H264_MB_TYPE_B_16x16;
+				nparts = 1;
+				pm0 = PM_L0 + t - 1u;
+			} else if (t <= 21) {
+				/* Table 7-14: types come in (16x8, 8x16) pairs that
+				 * share prediction modes; pair k = (t-4)/2:
+				 * 0 L0L0 1 L1L1 2 L0L1 3 L1L0 4 L0Bi 5 L1Bi
+				 * 6 BiL0 7 BiL1 8 BiBi; 2 bits each: 0 L0 1 L1 2 Bi */
+				uint32_t k = (t - 4u) >> 1;
+				mb_type = (t & 1u) ? H264_MB_TYPE_B_8x16
+						   : H264_MB_TYPE_B_16x8;
+				nparts = 2;
+				pm0 = PM_L0 + ((0x2A444u >> (2u * k)) & 3u);
+				pm1 = PM_L0 + ((0x24A14u >> (2u * k)) & 3u);
+			} else if (t == 22) {
+				mb_type = H264_MB_TYPE_B_8x8;
+				nparts = 4;
+			} else {
+				t -= 23;
+				intra = true;
+			}
+		}
+		if (intra) {
+			if (t == 0) {
+				mb_type = H264_MB_TYPE_I_NxN;
+				nparts = 1;
+				pm0 = PM_I4x4;
+			} else if (t <= 24) {
+				mb_type = H264_MB_TYPE_I_16x16;
+				nparts = 1;
+				pm0 = PM_I16x16;
+				i16pred = (t - 1u) & 3u;
+				cbp_luma = t <= 12 ? 0u : 15u;
+				cbp_chroma = ((t - 1u) >> 2) % 3u;
+			} else if (t == 25) {
+				mb_type = H264_MB_TYPE_I_PCM;
+				nparts = 0;
+			} else {
+				return -EIO;
+			}
+		}
+
+		uint32_t flags = 0, icp = 0;
+		int32_t qpd = 0;
+		uint32_t pred_lo = 0, pred_hi = 0; /* pred[8] of the summary */
+
+		if (mb_type == H264_MB_TYPE_I_PCM) {
+			/* pcm_alignment_zero_bit, then raw samples (:622-645) */
+			uint32_t p = wb_pos(wb) & 7u;
+			if (p && wb_u(wb, lane, 8u - p) != 0)
+				return -EIO;
+			uint32_t total = 256u + 2u * S.pcm_chroma;
+			for (uint32_t k = 0; k < total; k++) {
+				if ((k & 15u) == 0) {
+					wb_sync(wb, lane);
+					if (wb_overrun(wb))
+						return -EIO;
+				}
+				uint32_t smp = wb_u(wb, lane, k < 256u ? S.bdl : S.bdc);
+				lds_w16(stage, H264_AMD_T2_HEAD + 2u * k, smp, lane);
+			}
+			m.cur = lane < 48 ? 16u : 0u;
+		} else {
+			bool no_sub8 = true;
+			if (mb_type != H264_MB_TYPE_I_NxN && pm0 != PM_I16x16 &&
+			    nparts == 4) {
+				/* ---- sub_mb_pred (:422-503) ---- */
+				uint32_t sub_pm[4], sub_n[4];
+#pragma unroll
+				for (uint32_t p = 0; p < 4; p++) {
+					uint32_t st;
+					RD_UE(st);
+					pred_lo |= (st & 0xffu) << (8u * p);
+					if (is_b) {
+						if (st >= 13)
+							return -EIO;
+						/* Table 7-18 */
+						sub_pm[p] = st == 0   ? (uint32_t)PM_DIRECT
+							    : st <= 3 ? PM_L0 + st - 1u
+							    : st <= 9 ? PM_L0 + ((st - 4u) >> 1)
+								      : PM_L0 + st - 10u;
+						sub_n[p] = st == 0   ? 4u
+							   : st <= 3 ? 1u
+							   : st <= 9 ? 2u
+								     : 4u;
+					} else {
+						if (st >= 4)
+							return -EIO;
+						sub_pm[p] = PM_L0;
+						sub_n[p] = st == 0 ? 1u : st == 3 ? 4u : 2u;
+					}
+					if (sub_pm[p] != PM_DIRECT) {
+						if (sub_n[p] > 1)
+							no_sub8 = false;
+					} else if (!S.direct8x8) {
+						no_sub8 = false;
+					}
+				}
+				if (S.nref0 > 0 && mb_type != H264_MB_TYPE_P_8x8ref0) {
+#pragma unroll
+					for (uint32_t p = 0; p < 4; p++)
+						if (sub_pm[p] != PM_DIRECT &&
+						    sub_pm[p] != PM_L1) {
+							uint32_t r = wb_te(wb, lane, S.nref0, ok);
+							if (!ok)
+								return -EIO;
+							lds_w8(stage, 64 + p, r, lane);
+						}
+				}
+				if (S.nref1 > 0) {
+#pragma unroll
+					for (uint32_t p = 0; p < 4; p++)
+						if (sub_pm[p] != PM_DIRECT &&
+						    sub_pm[p] != PM_L0) {
+							uint32_t r = wb_te(wb, lane, S.nref1, ok);
+							if (!ok)
+								return -EIO;
+							lds_w8(stage, 68 + p, r, lane);
+						}
+				}
+#pragma unroll
+				for (uint32_t l = 0; l < 2; l++) {
+#pragma unroll
+					for (uint32_t p = 0; p < 4; p++) {
+						if (sub_pm[p] == PM_DIRECT ||
+						    sub_pm[p] == (l ? PM_L0 : PM_L1))
+							continue;
+						wb_sync(wb, lane);
+						for (uint32_t s = 0; s < sub_n[p]; s++)
+							for (uint32_t c = 0; c < 2; c++) {
+								int32_t d;
+								RD_SE(d);
+								lds_w16(stage,
+									128 + 64 * l + 16 * p + 4 * s + 2 * c,
+									(uint32_t)d, lane);
+							}
+					}
+				}
+			} else {
+				/* ---- mb_pred (:506-601) ---- */
+				if (S.t8x8_mode && mb_type == H264_MB_TYPE_I_NxN) {
+					if (wb_u1(wb, lane)) {
+						flags |= H264_AMD_MB_TRANSFORM_8X8;
+						pm0 = PM_I8x8;
+					}
+				}
+				if (pm0 == PM_I4x4 || pm0 == PM_I8x8 || pm0 == PM_I16x16) {
+					if (pm0 != PM_I16x16) {
+						uint32_t n = pm0 == PM_I4x4 ? 16u : 4u;
+						for (uint32_t b = 0; b < n; b++) {
+							uint32_t nib = 0;
+							if (!wb_u1(wb, lane))
+								nib = wb_u(wb, lane, 3) + 1u;
+							if (b < 8)
+								pred_lo |= nib << (4u * b);
+							else
+								pred_hi |= nib << (4u * (b - 8u));
+						}
+					}
+					if (chroma12)
+						RD_UE(icp);
+				} else if (pm0 != PM_DIRECT) {
+					if (S.nref0 > 0) {
+						for (uint32_t p = 0; p < nparts; p++)
+							if ((p ? pm1 : pm0) != PM_L1) {
+								uint32_t r = wb_te(wb, lane, S.nref0, ok);
+								if (!ok)
+									return -EIO;
+								lds_w8(stage, 64 + p, r, lane);
+							}
+					}
+					if (S.nref1 > 0) {
+						for (uint32_t p = 0; p < nparts; p++)
+							if ((p ? pm1 : pm0) != PM_L0) {
+								uint32_t r = wb_te(wb, lane, S.nref1, ok);
+								if (!ok)
+									return -EIO;
+								lds_w8(stage, 68 + p, r, lane);
+							}
+					}
+					for (uint32_t l = 0; l < 2; l++)
+						for (uint32_t p = 0; p < nparts; p++) {
+							if ((p ? pm1 : pm0) == (l ? PM_L0 : PM_L1))
+								continue;
+							for (uint32_t c = 0; c < 2; c++) {
+								int32_t d;
+								RD_SE(d);
+								lds_w16(stage, 128 + 64 * l + 16 * p + 2 * c,
+									(uint32_t)d, lane);
+							}
+						}
+				}
+			}
+			wb_sync(wb, lane);
+			if (pm0 != PM_I16x16) {
+				/* coded_block_pattern, me(v) mapping of Table 9-4
+				 * (src/h264_slice_data.c:1041-1080); cbp_map lane =
+				 * codeNum, bytes: cat 1/2 intra, inter, cat 0/3
+				 * intra, inter */
+				uint32_t code;
+				RD_UE(code);
+				if (cat > 3 || code >= (chroma12 ? 48u : 16u))
+					return -EIO;
+				bool intra_col = mb_type == H264_MB_TYPE_I_NxN ||
+						 mb_type == H264_MB_TYPE_SI;
+				uint32_t ent = (uint32_t)__builtin_amdgcn_readlane(
+					(int)cbp_map, (int)code);
+				uint32_t cbp = (ent >> (8u * ((chroma12 ? 0u : 2u) +
+							      (intra_col ? 0u : 1u)))) &
+					       0xffu;
+				cbp_luma = cbp & 15u;
+				cbp_chroma = cbp >> 4;
+				if (cbp_luma > 0 && S.t8x8_mode &&
+				    mb_type != H264_MB_TYPE_I_NxN && no_sub8 &&
+				    (mb_type != H264_MB_TYPE_B_Direct_16x16 ||
+				     S.direct8x8)) {
+					if (wb_u1(wb, lane))
+						flags |= H264_AMD_MB_TRANSFORM_8X8;
+				}
+			}
+			if (cbp_luma > 0 || cbp_chroma > 0 || pm0 == PM_I16x16) {
+				RD_SE(qpd);
+				/* ---- residual (:334-419): one loop over every
+				 * 4x4 block so that residual_block exists once ---- */
+				const bool i16 = pm0 == PM_I16x16;
+				const uint32_t luma_steps = 17u * (cat == 3 ? 3u : 1u);
+				const uint32_t steps =
+					luma_steps + (chroma12 ? 2u + 2u * nchroma : 0u);
+				uint32_t comp = 0, sub = 0; /* sub-step inside a comp */
+				for (uint32_t step = 0; step < steps; step++) {
+					uint32_t blk, maxnum, coef_off, nzlane;
+					uint32_t chroma_dc = 0, nC = 0;
+					bool coded;
+					if (step < luma_steps) {
+						if (sub == 0) {
+							/* Intra16x16 DC */
+							coded = i16;
+							blk = 0;
+							maxnum = 16;
+							coef_off = 256u * comp;
+						} else {
+							blk = sub - 1u;
+							coded = (cbp_luma >> (blk >> 2)) & 1u;
+							maxnum = i16 ? 15u : 16u;
+							coef_off = 256u * comp +
+								   (i16 ? 16u + 15u * blk : 16u * blk);
+						}
+						nzlane = 16u * comp + blk;
+						if (coded)
+							nC = sd_nc(m, comp, blk, 0, cat);
+						if (++sub == 17u) {
+							sub = 0;
+							comp++;
+						}
+					} else {
+						uint32_t c = step - luma_steps;
+						if (c < 2) {
+							coded = (cbp_chroma & 3u) != 0;
+							chroma_dc = cat; /* 1 or 2 */
+							maxnum = nchroma;
+							coef_off = 256u + nchroma * c;
+							blk = 0;
+							nzlane = 16u * (1u + c);
+						} else {
+							c -= 2;
+							uint32_t cc = c >= nchroma ? 1u : 0u;
+							blk = c - cc * nchroma;
+							coded = (cbp_chroma & 2u) != 0;
+							maxnum = 15;
+							coef_off = 256u + 2u * nchroma +
+								   15u * (nchroma * cc + blk);
+							nzlane = 16u * (1u + cc) + blk;
+							if (coded)
+								nC = sd_nc(m, 1u + cc, blk, 1, cat);
+						}
+					}
+					if (!coded)
+						continue;
+					wb_sync(wb, lane);
+					uint32_t tc;
+					int r = sd_residual_block(wb, vt, lane, stage, nC,
+								  chroma_dc, maxnum,
+								  coef_off, tc);
+					if (r)
+						return r;
+					/* TotalCoeff is recorded for every class, DC
+					 * blocks included (Appendix C.4) */
+					m.cur = wb_setlane(m.cur, nzlane, tc, lane);
+				}
+			}
+		}
+		if (wb_overrun(wb))
+			return -EIO;
+
+		/* ---- summary (struct h264_amd_mb_summary) ---- */
+		{
+			uint32_t word0 = mb_type | ((cbp_luma | (cbp_chroma << 4)) << 8) |
+					 (flags << 16) | ((raw_type & 0xffu) << 24);
+			uint32_t word1 = ((uint32_t)qpd & 0xffffu) |
+					 ((icp & 0xffu) << 16) | (i16pred << 24);
+			lds_w32(stage, 0, word0, lane);
+			lds_w32(stage, 4, word1, lane);
+			lds_w32(stage, 8, pred_lo, lane);
+			lds_w32(stage, 12, pred_hi, lane);
+			if (lane < 48)
+				stage[16u + lane] = (uint8_t)m.cur;
+		}
+		sd_emit_staged(o, stage, mbidx, lane);
+		sd_next_mb(m, row, mbx, W);
+		mbidx++;
+		mb_count = mbidx;
+	} while (wb_more_rbsp_data(wb, lane));
+	return 0;
+}
+
+/* ---- kernel ---------------------------------------------------------------- */
+
+struct sd_args {
+	const uint8_t *buf;
+	const struct h264_amd_slice_desc *descs;
+	uint32_t n;
+	const dev_sps *spsv;
+	const dev_pps *ppsv;
+	const dev_epoch *epochs;
+	uint32_t n_sps, n_pps, n_epochs;
+	const dev_vlc_tables *vlc;
+	uint32_t reader_flags, tier, mb_capacity, mb_stride;
+	struct h264_amd_slice_result *results;
+	struct h264_slice_header *headers;
+	uint8_t *mb_out;
+	uint32_t row_pitch; /* macroblock columns of row context in LDS */
+};
+
+extern "C" __global__ void __launch_bounds__(64)
+h264_amd_k_decode_slices(sd_args a)
+{
+	extern __shared__ __attribute__((aligned(16))) uint8_t lds[];
+	uint8_t *ring = lds + SD_RING_OFF;
+	uint8_t *stage = lds + SD_STAGE_OFF;
+	uint8_t *row = lds + SD_ROW_OFF;
+	const uint32_t lane = wb_lane();
+	const uint32_t slice = blockIdx.x;
+	if (slice >= a.n)
+		return;
+
+	struct h264_amd_slice_desc d;
+	sd_load_uniform(&d, a.descs + slice);
+	const uint32_t len = d.size;
+	const uint8_t *nal = a.buf + d.offset;
+
+	SliceState S;
+	S.cat = 1;
+	S.W = 1;
+	S.bdl = S.bdc = 8;
+	S.pcm_chroma = 0;
+	S.t8x8_mode = S.direct8x8 = S.entropy = S.unsupported = 0;
+	S.slice_type = 0;
+	S.first_mb = S.nref0 = S.nref1 = S.field_pic = 0;
+	S.slice_qp = 0;
+	S.nal_ref_idc = S.nal_unit_type = 0;
+	S.hdr_len_bits = S.rawdata_off = S.rawdata_len = S.partial = S.partialbits = 0;
+
+	int status = 0;
+	uint32_t rflags = 0, mb_count = 0, end_bit = 0;
+	OutCtx o;
+	o.tier = a.tier;
+	o.mb_stride = a.mb_stride;
+	o.rec_bytes = 1024;
+	o.mb_out = a.mb_out ? a.mb_out + (size_t)slice * a.mb_capacity * a.mb_stride
+			    : nullptr;
+	if (o.mb_out == nullptr)
+		o.tier = H264_AMD_TIER_NONE;
+	o.t0acc = 0;
+	o.lo = o.hi = 0;
+
+	/* header image starts as zeros (the reference memset()s it,
+	 * src/h264_syntax.h:1408-1410) */
+	for (uint32_t off = 16u * lane; off < SD_STAGE_BYTES; off += 1024u)
+		*reinterpret_cast<uint4 *>(stage + off) = make_uint4(0, 0, 0, 0);
+
+	WaveBits wb;
+	wb_open(wb, nal, len, ring, reinterpret_cast<uint32_t *>(lds + SD_STATE_OFF), lane);
+
+	/* NAL unit header (ref src/h264_syntax.h:1434-1443) */
+	if (len == 0) {
+		status = -EIO;
+	} else {
+		uint32_t h = wb_u(wb, lane, 8);
+		if (h & 0x80u)
+			status = -EIO;
+		S.nal_ref_idc = (h >> 5) & 3u;
+		S.nal_unit_type = h & 31u;
+		if (status == 0 && S.nal_unit_type != 1 && S.nal_unit_type != 5)
+			status = -EINVAL; /* not a slice: caller's mistake */
+	}
+
+	if (status == 0) {
+		uint32_t e = d.epoch < a.n_epochs ? d.epoch : 0u;
+		status = sd_slice_header(wb, lane, stage, S, a.spsv, a.ppsv,
+					 a.epochs + e, a.n_sps, a.n_pps);
+		if (status == 0 && wb_overrun(wb))
+			status = -EIO;
+	}
+	if (status == 0) {
+		/* ctx->slice.hdr_len and rawdata (src/h264_syntax.h:1383,
+		 * src/h264_syntax_slice_data.h:803-806) */
+		uint32_t P = wb_pos(wb);
+		uint32_t k = (P + 7u) / 8u - 1u; /* last RBSP byte touched */
+		uint32_t raw_after = wb_raw_of_clean(wb, k, lane) + 1u;
+		S.partialbits = (8u - (P & 7u)) & 7u;
+		/* bs->cache holds the whole last byte (it may lie just before
+		 * the window, but the ring still has it) */
+		S.partial = wb_uniform(ring[k & (WB_RING_BYTES - 1)]);
+		S.hdr_len_bits = 8u * raw_after - S.partialbits;
+		S.rawdata_off = raw_after;
+		S.rawdata_len = len - raw_after;
+		rflags |= H264_AMD_SR_HEADER_OK;
+		if (S.entropy)
+			rflags |= H264_AMD_SR_CABAC;
+		end_bit = P;
+		o.rec_bytes = sd_t2_stride(S.cat);
+		if (a.headers) {
+			uint8_t *dst = reinterpret_cast<uint8_t *>(a.headers + slice);
+			for (uint32_t off = 16u * lane;
+			     off < sizeof(struct h264_slice_header); off += 1024u)
+				*reinterpret_cast<uint4 *>(dst + off) =
+					*reinterpret_cast<const uint4 *>(stage + off);
+		}
+		if ((a.reader_flags & H264_READER_FLAGS_SLICE_DATA) && !S.entropy) {
+			if (S.unsupported) {
+				status = H264_AMD_E_UNSUPPORTED;
+			} else if (S.W == 0 || S.W > a.row_pitch) {
+				status = H264_AMD_E_UNSUPPORTED;
+			} else {
+				rflags |= H264_AMD_SR_DATA_PARSED;
+				VlcLanes vt;
+				vlc_load(vt, a.vlc, lane);
+				uint32_t cbp_map = a.vlc->e[VLC_ROWS][lane];
+				status = sd_slice_data(wb, vt, cbp_map, lane, stage,
+						       row, S, o, a.mb_capacity,
+						       mb_count);
+				end_bit = wb_pos(wb);
+			}
+		}
+	}
+
+	/* T0: flush the partial last group of 64 words */
+	if (o.tier == H264_AMD_TIER_T0 && (mb_count & 63u) != 0) {
+		uint32_t base = mb_count & ~63u;
+		if (base + lane < mb_count)
+			*reinterpret_cast<uint32_t *>(
+				o.mb_out + (size_t)(base + lane) * o.mb_stride) = o.t0acc;
+	}
+
+	/* wave reduction of the checksum halves */
+	uint32_t lo = o.lo, hi = o.hi;
+#pragma unroll
+	for (int sft = 32; sft >= 1; sft >>= 1) {
+		lo += (uint32_t)__shfl_xor((int)lo, sft);
+		hi += (uint32_t)__shfl_xor((int)hi, sft);
+	}
+
+	if (lane == 0) {
+		struct h264_amd_slice_result r;
+		r.status = status;
+		r.flags = rflags;
+		r.nal_ref_idc = S.nal_ref_idc;
+		r.nal_unit_type = S.nal_unit_type;
+		r.slice_type = (rflags & H264_AMD_SR_HEADER_OK) ? (int32_t)S.slice_type : -1;
+		r.first_mb_in_slice = (rflags & H264_AMD_SR_HEADER_OK) ? S.first_mb : 0u;
+		r.mb_count = mb_count;
+		r.slice_qp = (rflags & H264_AMD_SR_HEADER_OK) ? S.slice_qp : 0;
+		r.hdr_len_bits = S.hdr_len_bits;
+		r.rawdata_off = S.rawdata_off;
+		r.rawdata_len = S.rawdata_len;
+		r.partial = (uint8_t)S.partial;
+		r.partialbits = (uint8_t)S.partialbits;
+		r.chroma_array_type =
+			(rflags & H264_AMD_SR_HEADER_OK) ? (uint16_t)S.cat : (uint16_t)0;
+		r.end_bit = status == 0 ? end_bit : 0u;
+		r.pic_width_in_mbs = (rflags & H264_AMD_SR_HEADER_OK) ? S.W : 0u;
+		r.checksum = ((uint64_t)hi << 32) | lo;
+		a.results[slice] = r;
+	}
+}
+

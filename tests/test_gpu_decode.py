@@ -1,0 +1,113 @@
+"""GPU parity: slice decode kernel vs the oracle (and vs the generator's own
+expectation) through the C-ABI.  Bit-exact: integer/byte work."""
+import ctypes as C
+
+import numpy as np
+import pytest
+
+import orc
+import streams
+from libh264_amd import gen, Params
+from libh264_amd.ctypes_abi import (Sps, Pps, SliceHeader, SliceResult,
+                                    TIER_NONE, TIER_T0, TIER_T1, TIER_T2,
+                                    t2_stride)
+
+pytestmark = pytest.mark.gpu
+
+
+def result_fields(r):
+    return {n: getattr(r, n) for n, _ in SliceResult._fields_}
+
+
+def make_params(oracle_rec):
+    p = Params()
+    for ev in oracle_rec.events:
+        if ev.kind == 8:
+            p.put_sps(oracle_rec.sps[ev.a])
+        elif ev.kind == 9:
+            p.put_pps(oracle_rec.pps[ev.a])
+    return p
+
+
+def run_case(engine, cfg, slices, tier, lead=0, flags=1):
+    sps, pps = gen.sps(cfg), gen.pps(cfg)
+    nals, expect = [], []
+    for s in slices:
+        n, e = gen.slice_nal(cfg, s, want_t2=True)
+        nals.append(n)
+        expect.append(e)
+    ref = orc.parse_nalus([sps, pps] + nals, flags=flags)
+    assert ref.statuses[0] == 0 and ref.statuses[1] == 0
+    params = make_params(ref)
+    buf, offs, sizes = streams.pack_nals(nals, lead=lead)
+    d_buf = engine.upload(buf)
+    descs = [(o, s, params.epoch) for o, s in zip(offs, sizes)]
+    cap = max(s.num_mbs for s in slices) + 2
+    out = engine.decode_slices(params, d_buf, descs, reader_flags=flags,
+                               tier=tier, mb_capacity=cap, want_headers=True)
+    res = engine.fetch_results(out)
+    hdrs = engine.fetch_headers(out)
+    for i, s in enumerate(slices):
+        want = result_fields(ref.results[i])
+        got = result_fields(res[i])
+        assert got == want, (i, got, want)
+        assert bytes(hdrs[i]) == bytes(ref.headers[i]), i
+        if flags == 0:
+            continue
+        assert res[i].mb_count == s.num_mbs
+        if tier == TIER_T2:
+            mb = engine.fetch_mb(out, i, res[i].mb_count)
+            st = t2_stride(res[i].chroma_array_type)
+            got_mb = mb[:, :st]
+            assert np.array_equal(got_mb, ref.mb_records(i)), i
+            assert np.array_equal(got_mb, expect[i]), i
+        elif tier == TIER_T1:
+            mb = engine.fetch_mb(out, i, res[i].mb_count)
+            assert np.array_equal(mb, ref.mb_records(i)[:, :64]), i
+        elif tier == TIER_T0:
+            mb = engine.fetch_mb(out, i, res[i].mb_count)
+            assert np.array_equal(mb, ref.mb_records(i)[:, :4]), i
+    return res
+
+
+@pytest.mark.parametrize("tier", [TIER_T2, TIER_T1, TIER_T0, TIER_NONE])
+def test_ipb_slices_420(engine, tier):
+    cfg = streams.small_cfg()
+    slices = [streams.rich_slice(cfg, seed, st,
+                                 first_mb=0 if seed % 3 else 5)
+              for seed in range(24) for st in (2, 0, 1)]
+    run_case(engine, cfg, slices, tier)
+
+
+@pytest.mark.parametrize("cf,bd", [(0, 0), (2, 0), (3, 0), (1, 2), (3, 4)])
+def test_chroma_formats(engine, cf, bd):
+    cfg = streams.small_cfg(cf=cf, bd=bd, weighted_pred_flag=1,
+                            weighted_bipred_idc=1,
+                            num_ref_idx_l1_default_minus1=2,
+                            direct_8x8_inference_flag=0,
+                            deblocking_filter_control_present_flag=0)
+    slices = [streams.rich_slice(cfg, seed, st + 5 * (seed % 2),
+                                 first_mb=seed % 7, pm_pcm=60)
+              for seed in range(12) for st in (2, 0, 1)]
+    run_case(engine, cfg, slices, TIER_T2)
+
+
+@pytest.mark.parametrize("lead", [1, 2, 3])
+def test_unaligned_nal_start(engine, lead):
+    cfg = streams.small_cfg()
+    slices = [streams.rich_slice(cfg, 100 + seed, 2) for seed in range(6)]
+    run_case(engine, cfg, slices, TIER_T2, lead=lead)
+
+
+def test_header_only(engine):
+    cfg = streams.small_cfg()
+    slices = [streams.rich_slice(cfg, seed, st)
+              for seed in range(8) for st in (2, 0, 1)]
+    run_case(engine, cfg, slices, TIER_NONE, flags=0)
+
+
+def test_1080p_slice(engine):
+    cfg = gen.cfg_1080p()
+    slices = [streams.rich_slice(cfg, 7, 7, pm_pcm=2, density=5,
+                                 pm_escape=5, hdr_extras=0)]
+    run_case(engine, cfg, slices, TIER_T2)
