@@ -62,6 +62,14 @@ static int hip_err(hipError_t e)
 
 enum { FAM_SCAN, FAM_DECODE, FAM_WRITE, FAM_SYNTH, FAM_COUNT };
 
+/* Serial numbers are process-wide so that a params object allocated at the
+ * address of a freed one can never look "unchanged" to an engine's cache. */
+static uint64_t next_serial(void)
+{
+	static uint64_t g_serial;
+	return __atomic_add_fetch(&g_serial, 1, __ATOMIC_RELAXED);
+}
+
 struct h264_amd_params {
 	std::vector<h264_sps> sps_full;
 	std::vector<h264_pps> pps_full;
@@ -361,7 +369,7 @@ extern "C" int h264_amd_params_reset(struct h264_amd_params *p)
 	dev_epoch e0;
 	memset(&e0, 0xff, sizeof(e0)); /* every id: DEV_NO_VERSION */
 	p->epochs.push_back(e0);
-	p->serial++;
+	p->serial = next_serial();
 	p->max_width_mbs = 1;
 	p->max_pic_mbs = 1;
 	return 0;
@@ -405,7 +413,7 @@ extern "C" int h264_amd_params_put_sps(struct h264_amd_params *p,
 	dev_epoch ne = cur;
 	ne.sps_ver[sps->seq_parameter_set_id] = (uint16_t)(p->sps.size() - 1);
 	p->epochs.push_back(ne);
-	p->serial++;
+	p->serial = next_serial();
 	if (d.pic_width_in_mbs > p->max_width_mbs)
 		p->max_width_mbs = d.pic_width_in_mbs;
 	uint64_t mbs = (uint64_t)d.pic_width_in_mbs * d.pic_height_in_map_units *
@@ -456,7 +464,7 @@ extern "C" int h264_amd_params_put_pps(struct h264_amd_params *p,
 	dev_epoch ne = cur;
 	ne.pps_ver[pps->pic_parameter_set_id] = (uint16_t)(p->pps.size() - 1);
 	p->epochs.push_back(ne);
-	p->serial++;
+	p->serial = next_serial();
 	return h264_amd_params_epoch(p);
 }
 

@@ -27,8 +27,7 @@ def lib():
     global _LIB
     if _LIB is None:
         path = os.path.join(ROOT, "oracle", "build", "liboracle.so")
-        if not os.path.exists(path):
-            build()
+        build()  # make is a no-op when the library is up to date
         L = C.CDLL(path)
         L.orc_rec_new.restype = C.c_void_p
         L.orc_rec_new.argtypes = [C.c_uint32, C.c_uint32]
