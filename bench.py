@@ -1,0 +1,276 @@
+#!/usr/bin/env python3
+"""bench.py -- BASELINE.json headline metric on MI355X.
+
+Workload (config.workload "C2"): a batch of independent 1080p Baseline-profile
+CAVLC I-slices (1920x1088, 8160 macroblocks each), one slice per wavefront,
+decoded by the hand-written gfx950 kernel h264_amd_k_decode_slices through the
+C-ABI (h264_amd_decode_slices).  A "step" is one launch over the whole batch:
+slice header + complete CAVLC slice_data walk of every slice, T0 macroblock
+records and the per-slice checksum over the full macroblock syntax written
+back.  Inputs are resident in HBM before the timed region.
+
+  python bench.py [--gpus N] [--steps K] [--warmup W] [--slices S]
+
+N > 1: one process per GPU (torch.distributed, backend nccl = RCCL), the batch
+is sharded by slice with no data-path collective (slices are independent,
+SURVEY.md 8(e)); weak scaling: every rank decodes S slices.  value = bits of
+all ranks / max-over-ranks time.
+
+Prints ONE JSON line (rank 0).  roofline.achieved = slice bytes read per launch
+/ average kernel time from HIP events on the launch stream; cpu_baseline = the
+oracle's reader (kind "port") on a bounded sample, all host cores.
+"""
+import argparse
+import ctypes as C
+import json
+import os
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+sys.path.insert(0, os.path.join(ROOT, "tests"))
+
+HBM_PEAK_GBS = 8000.0  # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
+
+
+def make_workload(n_slices, seed0, threads):
+    from libh264_amd import gen
+    from libh264_amd.ctypes_abi import GenSlice
+    cfg = gen.cfg_1080p()
+    slices = []
+    for i in range(n_slices):
+        s = GenSlice(slice_type=7, idr=1, nal_ref_idc=3, first_mb=0,
+                     num_mbs=8160, frame_num=0, idr_pic_id=(seed0 + i) & 0xff,
+                     pm_i16x16=280, pm_pcm=2, density=5, pm_escape=5,
+                     pm_cbp_zero=50, pm_zero_pcm=100, seed=seed0 + i)
+        slices.append(s)
+    buf, offs, sizes = gen.batch(cfg, slices, threads=threads)
+    return cfg, buf, offs, sizes
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=5)
+    ap.add_argument("--warmup", type=int, default=2)
+    ap.add_argument("--slices", type=int, default=4096,
+                    help="slices per GPU (BASELINE config 2: 4096)")
+    ap.add_argument("--tier", type=int, default=1, help="0 none, 1 T0, 2 T1")
+    ap.add_argument("--verify", type=int, default=16,
+                    help="slices re-parsed by the oracle after the run")
+    ap.add_argument("--cpu-sample", type=int, default=0,
+                    help="slices in the CPU baseline sample (0 = auto)")
+    args = ap.parse_args()
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    dist = None
+    if world > 1:
+        import torch
+        import torch.distributed as dist_mod
+        dist = dist_mod
+        torch.cuda.set_device(local_rank)
+        dist.init_process_group(backend="nccl")
+    n_gpus = world
+
+    import libh264_amd
+    from libh264_amd import gen, Params
+    from libh264_amd.ctypes_abi import Sps, Pps, TIER_NONE, TIER_T0, TIER_T1
+
+    # a GPU box gives each GPU a share of 16 host cores whatever os.cpu_count()
+    # says; the CPU baseline and the generator stay inside that share
+    try:
+        avail = len(os.sched_getaffinity(0))
+    except AttributeError:
+        avail = os.cpu_count() or 1
+    cores = max(1, min(avail, int(os.environ.get("H264_AMD_HOST_CORES", "16"))))
+    threads = cores
+    t0 = time.time()
+    cfg, buf, offs, sizes = make_workload(args.slices, 1000003 * rank + 17,
+                                          threads)
+    gen_s = time.time() - t0
+    total_bytes = int(sizes.sum())
+    total_mbs = 8160 * args.slices
+
+    eng = libh264_amd.Engine(local_rank)
+    # parameter sets: parse the generator's SPS/PPS bytes with the oracle-free
+    # host parser of the product when available, else fill from the config
+    sps_nal, pps_nal = gen.sps(cfg), gen.pps(cfg)
+    sps, pps = Sps(), Pps()
+    sps.profile_idc = cfg.profile_idc
+    sps.level_idc = cfg.level_idc
+    sps.chroma_format_idc = 1
+    sps.pic_order_cnt_type = cfg.pic_order_cnt_type
+    sps.max_num_ref_frames = cfg.max_num_ref_frames
+    sps.pic_width_in_mbs_minus1 = cfg.width_mbs - 1
+    sps.pic_height_in_map_units_minus1 = cfg.height_mbs - 1
+    sps.frame_mbs_only_flag = 1
+    sps.direct_8x8_inference_flag = cfg.direct_8x8_inference_flag
+    sps.frame_cropping_flag = 1
+    sps.frame_crop_bottom_offset = cfg.crop_bottom
+    pps.deblocking_filter_control_present_flag = \
+        cfg.deblocking_filter_control_present_flag
+    params = Params()
+    params.put_sps(sps)
+    epoch = params.put_pps(pps)
+
+    # largest slices first: the last wavefronts to start are the shortest
+    order = np.argsort(-sizes.astype(np.int64), kind="stable")
+    descs = np.zeros(args.slices, dtype=[("offset", "<u8"), ("size", "<u4"),
+                                         ("epoch", "<u4")])
+    descs["offset"] = offs[order]
+    descs["size"] = sizes[order]
+    descs["epoch"] = epoch
+    d_buf = eng.upload(buf)
+    d_descs = eng.upload(descs)
+    tier = {0: TIER_NONE, 1: TIER_T0, 2: TIER_T1}[args.tier]
+    out = eng.decode_slices(params, d_buf, descs, reader_flags=1, tier=tier,
+                            mb_capacity=8160, d_descs=d_descs)
+
+    def barrier():
+        eng.sync()
+        if dist is not None:
+            import torch
+            torch.cuda.synchronize()
+            dist.barrier()
+
+    for _ in range(args.warmup):
+        eng.decode_slices(params, d_buf, descs, reader_flags=1, tier=tier,
+                          mb_capacity=8160, d_descs=d_descs, outputs=out)
+    barrier()
+    kernel_ms = []
+    t_start = time.perf_counter()
+    for _ in range(args.steps):
+        eng.decode_slices(params, d_buf, descs, reader_flags=1, tier=tier,
+                          mb_capacity=8160, d_descs=d_descs, outputs=out,
+                          sync=False)
+        kernel_ms.append(eng.last_kernel_ms("decode"))
+    barrier()
+    elapsed = time.perf_counter() - t_start
+    if dist is not None:
+        import torch
+        t = torch.tensor([elapsed], device="cuda")
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+
+    res = eng.fetch_results(out)
+    bad = [i for i in range(args.slices)
+           if res[i].status != 0 or res[i].mb_count != 8160]
+    if bad:
+        raise SystemExit("rank %d: %d slices failed on the GPU (first %d: "
+                         "status %d, %d MBs)" %
+                         (rank, len(bad), bad[0], res[bad[0]].status,
+                          res[bad[0]].mb_count))
+
+    # parity at full size: the oracle re-parses a sample and must reproduce the
+    # checksum over every macroblock's full syntax (checker only, not timed)
+    verified = 0
+    cpu = None
+    if rank == 0:
+        import orc
+        for j in range(min(args.verify, args.slices)):
+            k = j * (args.slices // max(1, min(args.verify, args.slices)))
+            i = int(order[k])  # result k belongs to generated slice i
+            nal = bytes(buf[int(offs[i]):int(offs[i]) + int(sizes[i])])
+            ref = orc.parse_nalus([sps_nal, pps_nal, nal], want=0)
+            r = ref.results[0]
+            g = res[k]
+            if (r.status, r.mb_count, r.checksum, r.end_bit, r.hdr_len_bits,
+                    r.rawdata_off) != (g.status, g.mb_count, g.checksum,
+                                       g.end_bit, g.hdr_len_bits,
+                                       g.rawdata_off):
+                raise SystemExit("parity failure on slice %d" % i)
+            verified += 1
+        if world == 1:
+            n_s = args.cpu_sample or min(args.slices, cores * 24)
+            sel = np.arange(n_s)
+            o = np.ascontiguousarray(offs[sel])
+            z = np.ascontiguousarray(sizes[sel])
+            secs, mbs, byts = C.c_double(), C.c_uint64(), C.c_uint64()
+            rc = orc.lib().orc_bench_slices(
+                buf.ctypes.data_as(C.c_void_p), o.ctypes.data_as(C.c_void_p),
+                z.ctypes.data_as(C.c_void_p), n_s, sps_nal, len(sps_nal),
+                pps_nal, len(pps_nal), 1, cores, C.byref(secs),
+                C.byref(mbs), C.byref(byts))
+            if rc != 0 or mbs.value != 8160 * n_s:
+                raise SystemExit("cpu baseline failed: rc %d" % rc)
+            cpu = {
+                "value": round(8.0 * byts.value / secs.value / 1e6, 1),
+                "unit": "Mbit/s",
+                "cores": cores,
+                "kind": "port",
+                "mb_per_s": round(mbs.value / secs.value, 1),
+                "sample": "%d of the same 1080p I-slices (%.1f MB), oracle "
+                          "reader with slice_data, one reader per thread, "
+                          "%.1f s wall" % (n_s, byts.value / 1e6, secs.value),
+            }
+
+    ms_per_step = 1e3 * elapsed / args.steps
+    if dist is not None:
+        import torch
+        tb = torch.tensor([float(total_bytes), float(total_mbs)],
+                          device="cuda", dtype=torch.float64)
+        dist.all_reduce(tb)
+        all_bytes, all_mbs = float(tb[0].item()), float(tb[1].item())
+    else:
+        all_bytes, all_mbs = float(total_bytes), float(total_mbs)
+    mbit_s = 8.0 * all_bytes * args.steps / elapsed / 1e6
+    k_ms = float(np.mean(kernel_ms))
+    achieved = total_bytes / (k_ms * 1e-3) / 1e9
+    out_bytes = args.slices * (64 + 8160 * out["stride"])
+
+    if rank == 0:
+        line = {
+            "metric": "bitstream_parsed_mbit_per_s",
+            "value": round(mbit_s, 1),
+            "unit": "Mbit/s",
+            "n_gpus": n_gpus,
+            "steps": args.steps,
+            "warmup": args.warmup,
+            "ms_per_step": round(ms_per_step, 3),
+            "higher_is_better": True,
+            "scaling": "weak",
+            "vs_baseline": None,
+            "dtype": "u8",
+            "data": "synthetic",
+            "macroblocks_per_s": round(all_mbs * args.steps / elapsed, 1),
+            "config": {
+                "workload": "C2: batch of %d independent 1080p Baseline CAVLC "
+                            "I-slices per GPU (8160 MBs each, mean %.0f "
+                            "bits/MB), one slice per wavefront" %
+                            (args.slices, 8.0 * total_bytes / total_mbs),
+                "slices_per_gpu": args.slices,
+                "bytes_per_gpu": total_bytes,
+                "output_tier": ["none", "T0", "T1"][args.tier],
+                "parallelism": "slices sharded over %d GPU(s), no data-path "
+                               "collective" % n_gpus,
+            },
+            "roofline": {
+                "bound": "hbm",
+                "kernel": "h264_amd_k_decode_slices",
+                "achieved": round(achieved, 2),
+                "peak": HBM_PEAK_GBS,
+                "unit": "GB/s",
+                "frac": round(achieved / HBM_PEAK_GBS, 5),
+                "traffic": None,
+                "kernel_ms": round(k_ms, 3),
+                "algorithmic_bytes_read": total_bytes,
+                "algorithmic_bytes_written": out_bytes,
+                "note": "CAVLC is a serial dependency chain per slice: the "
+                        "kernel is latency bound, not HBM bound",
+            },
+            "cpu_baseline": cpu,
+            "verified_slices_vs_oracle": verified,
+            "gen_seconds": round(gen_s, 1),
+        }
+        print(json.dumps(line), flush=True)
+    if dist is not None:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

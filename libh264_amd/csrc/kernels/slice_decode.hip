@@ -40,7 +40,8 @@
 
 #define SD_RING_OFF 0u
 #define SD_STATE_OFF 1024u
-#define SD_STAGE_OFF (1024u + WB_STATE_BYTES)
+#define SD_DUMP_OFF (1024u + WB_STATE_BYTES)
+#define SD_STAGE_OFF (SD_DUMP_OFF + 1024u) /* dump area right before stage */
 #define SD_STAGE_BYTES 4096u
 #define SD_ROW_OFF (SD_STAGE_OFF + SD_STAGE_BYTES)
 
@@ -58,25 +59,43 @@ struct SliceState {
 	uint32_t hdr_len_bits, rawdata_off, rawdata_len, partial, partialbits;
 };
 
+/* NO DIVERGENT BRANCHES in this kernel.  The whole design rests on the compiler
+ * proving the parse state wave-uniform; an `if (lane == 0) store` is a
+ * divergent branch, and once the optimiser merges its join block with the
+ * surrounding (uniform) control flow the cursor ends up in a phi "below a
+ * divergent branch", is declared divergent and drags the entire syntax walk
+ * onto the vector unit with exec-mask branches (measured: 2.6 k VALU + 3.1 k
+ * SALU instructions per macroblock).  So per-lane predication is done with
+ * ADDRESS selection instead: lanes that must not store write to a per-lane
+ * dump slot in LDS (or repeat a neighbour's identical store). */
+#define SD_DUMP_BYTES 1024u /* 64 lanes x 16 B */
+
+__device__ __forceinline__ uint8_t *lds_sel(uint8_t *real, uint8_t *dump,
+					    bool take, uint32_t lane)
+{
+	return take ? real : dump + 16u * lane;
+}
+
 __device__ __forceinline__ void lds_w32(uint8_t *p, uint32_t off, uint32_t v,
 					uint32_t lane)
 {
-	if (lane == 0)
-		*reinterpret_cast<uint32_t *>(p + off) = v;
+	uint8_t *dump = p - SD_DUMP_BYTES; /* the dump area precedes `stage` */
+	*reinterpret_cast<uint32_t *>(lds_sel(p + off, dump, lane == 0, lane)) = v;
 }
 
 __device__ __forceinline__ void lds_w16(uint8_t *p, uint32_t off, uint32_t v,
 					uint32_t lane)
 {
-	if (lane == 0)
-		*reinterpret_cast<uint16_t *>(p + off) = (uint16_t)v;
+	uint8_t *dump = p - SD_DUMP_BYTES;
+	*reinterpret_cast<uint16_t *>(lds_sel(p + off, dump, lane == 0, lane)) =
+		(uint16_t)v;
 }
 
 __device__ __forceinline__ void lds_w8(uint8_t *p, uint32_t off, uint32_t v,
 				       uint32_t lane)
 {
-	if (lane == 0)
-		p[off] = (uint8_t)v;
+	uint8_t *dump = p - SD_DUMP_BYTES;
+	*lds_sel(p + off, dump, lane == 0, lane) = (uint8_t)v;
 }
 
 #define HOFF(f) ((uint32_t)offsetof(struct h264_slice_header, f))
@@ -547,19 +566,21 @@ __device__ __forceinline__ int sd_residual_block(WaveBits &wb, const VlcLanes &v
 	bool mine = lane < tc;
 	if (__ballot(mine && pos >= maxnum))
 		return -EIO; /* malformed: outside the block (Appendix C.5) */
-	if (mine)
-		*reinterpret_cast<uint16_t *>(stage + H264_AMD_T2_HEAD +
-					      2u * (coef_off + pos)) = (uint16_t)lv;
+	*reinterpret_cast<uint16_t *>(
+		lds_sel(stage + H264_AMD_T2_HEAD + 2u * (coef_off + pos),
+			stage - SD_DUMP_BYTES, mine, lane)) = (uint16_t)lv;
 	return 0;
 }
 
-/* checksum terms of the staged record; a_w/b_w hold the multipliers of this
- * lane's 8 words for the CURRENT macroblock index (stepped by the caller) */
-__device__ __forceinline__ void sd_checksum(const uint4 q, uint32_t abase,
-					    uint32_t bbase, uint32_t &lo,
+/* checksum terms of 8 consecutive 16-bit words starting at word index idx */
+__device__ __forceinline__ void sd_checksum(const uint4 q, uint32_t idx,
+					    bool valid, uint32_t &lo,
 					    uint32_t &hi)
 {
 	const uint32_t d[4] = {q.x, q.y, q.z, q.w};
+	const uint32_t abase = idx * 0x9E3779B1u + 0x85EBCA77u;
+	const uint32_t bbase = idx * 0xC2B2AE3Du + 0x27D4EB2Fu;
+	uint32_t l = 0, h = 0;
 #pragma unroll
 	for (int k = 0; k < 4; k++) {
 		uint32_t w0 = d[k] & 0xffffu, w1 = d[k] >> 16;
@@ -567,9 +588,11 @@ __device__ __forceinline__ void sd_checksum(const uint4 q, uint32_t abase,
 		uint32_t a1 = a0 + 0x9E3779B1u;
 		uint32_t b0 = bbase + (uint32_t)(2 * k) * 0xC2B2AE3Du;
 		uint32_t b1 = b0 + 0xC2B2AE3Du;
-		lo += w0 * a0 + w1 * a1;
-		hi += (w0 * (w0 + 1u)) * b0 + (w1 * (w1 + 1u)) * b1;
+		l += w0 * a0 + w1 * a1;
+		h += (w0 * (w0 + 1u)) * b0 + (w1 * (w1 + 1u)) * b1;
 	}
+	lo += valid ? l : 0u;
+	hi += valid ? h : 0u;
 }
 
 struct OutCtx {
@@ -579,72 +602,72 @@ struct OutCtx {
 	uint32_t lo, hi; /* per lane checksum partials */
 };
 
-/* Finish one macroblock whose record is staged in LDS. */
+/* T0: one word per macroblock, flushed 64 at a time (256-byte stores) */
+__device__ __forceinline__ void sd_t0_put(OutCtx &o, uint32_t word0,
+					  uint32_t mbidx, uint32_t lane)
+{
+	o.t0acc = wb_setlane(o.t0acc, mbidx & 63u, word0, lane);
+	if ((mbidx & 63u) == 63u)
+		*reinterpret_cast<uint32_t *>(
+			o.mb_out + (size_t)(mbidx - 63u + lane) * o.mb_stride) = o.t0acc;
+}
+
+/* Finish one macroblock whose record is staged in LDS.  Lanes beyond the end
+ * of the record repeat the store of its last 16 bytes (same address, same
+ * data) instead of being masked off: no divergent branch. */
 __device__ __forceinline__ void sd_emit_staged(OutCtx &o, const uint8_t *stage,
 					       uint32_t mbidx, uint32_t lane)
 {
-	uint32_t word0 = *reinterpret_cast<const uint32_t *>(stage);
+	uint32_t word0 = wb_uniform(*reinterpret_cast<const uint32_t *>(stage));
 	for (uint32_t part = 0; part * 1024u < o.rec_bytes; part++) {
-		uint32_t off = part * 1024u + 16u * lane;
-		if (off < o.rec_bytes) {
-			uint4 q = *reinterpret_cast<const uint4 *>(stage + off);
-			uint32_t idx = mbidx * 1024u + off / 2u;
-			sd_checksum(q, idx * 0x9E3779B1u + 0x85EBCA77u,
-				    idx * 0xC2B2AE3Du + 0x27D4EB2Fu, o.lo, o.hi);
-			if (o.tier == H264_AMD_TIER_T2)
-				*reinterpret_cast<uint4 *>(
-					o.mb_out + (size_t)mbidx * o.mb_stride + off) = q;
-		}
+		uint32_t want = part * 1024u + 16u * lane;
+		bool valid = want < o.rec_bytes;
+		uint32_t off = valid ? want : o.rec_bytes - 16u;
+		uint4 q = *reinterpret_cast<const uint4 *>(stage + off);
+		sd_checksum(q, mbidx * 1024u + off / 2u, valid, o.lo, o.hi);
+		if (o.tier == H264_AMD_TIER_T2)
+			*reinterpret_cast<uint4 *>(
+				o.mb_out + (size_t)mbidx * o.mb_stride + off) = q;
 	}
-	if (o.tier == H264_AMD_TIER_T1 && lane < 16)
+	if (o.tier == H264_AMD_TIER_T1) {
+		uint32_t l = lane & 15u;
 		*reinterpret_cast<uint32_t *>(o.mb_out + (size_t)mbidx * o.mb_stride +
-					      4u * lane) =
-			*reinterpret_cast<const uint32_t *>(stage + 4u * lane);
-	if (o.tier == H264_AMD_TIER_T0) {
-		o.t0acc = wb_setlane(o.t0acc, mbidx & 63u, word0, lane);
-		if ((mbidx & 63u) == 63u)
-			*reinterpret_cast<uint32_t *>(
-				o.mb_out + (size_t)(mbidx - 63u + lane) * o.mb_stride) =
-				o.t0acc;
+					      4u * l) =
+			*reinterpret_cast<const uint32_t *>(stage + 4u * l);
 	}
+	if (o.tier == H264_AMD_TIER_T0)
+		sd_t0_put(o, word0, mbidx, lane);
 }
 
 /* A skipped macroblock: the record is word0 followed by zeros. */
 __device__ __forceinline__ void sd_emit_skipped(OutCtx &o, uint32_t word0,
 						uint32_t mbidx, uint32_t lane)
 {
-	if (lane == 0) {
-		uint32_t idx = mbidx * 1024u;
-		uint4 q = make_uint4(word0, 0, 0, 0);
-		sd_checksum(q, idx * 0x9E3779B1u + 0x85EBCA77u,
-			    idx * 0xC2B2AE3Du + 0x27D4EB2Fu, o.lo, o.hi);
-	}
+	sd_checksum(make_uint4(word0, 0, 0, 0), mbidx * 1024u, lane == 0, o.lo,
+		    o.hi);
 	if (o.tier == H264_AMD_TIER_T2) {
-		for (uint32_t off = 16u * lane; off < o.rec_bytes; off += 1024u) {
+		for (uint32_t part = 0; part * 1024u < o.rec_bytes; part++) {
+			uint32_t want = part * 1024u + 16u * lane;
+			uint32_t off = want < o.rec_bytes ? want : o.rec_bytes - 16u;
 			uint4 q = make_uint4(off == 0 ? word0 : 0u, 0, 0, 0);
 			*reinterpret_cast<uint4 *>(
 				o.mb_out + (size_t)mbidx * o.mb_stride + off) = q;
 		}
 	} else if (o.tier == H264_AMD_TIER_T1) {
-		if (lane < 16)
-			*reinterpret_cast<uint32_t *>(
-				o.mb_out + (size_t)mbidx * o.mb_stride + 4u * lane) =
-				lane == 0 ? word0 : 0u;
+		uint32_t l = lane & 15u;
+		*reinterpret_cast<uint32_t *>(o.mb_out + (size_t)mbidx * o.mb_stride +
+					      4u * l) = l == 0 ? word0 : 0u;
 	} else if (o.tier == H264_AMD_TIER_T0) {
-		o.t0acc = wb_setlane(o.t0acc, mbidx & 63u, word0, lane);
-		if ((mbidx & 63u) == 63u)
-			*reinterpret_cast<uint32_t *>(
-				o.mb_out + (size_t)(mbidx - 63u + lane) * o.mb_stride) =
-				o.t0acc;
+		sd_t0_put(o, word0, mbidx, lane);
 	}
 }
 
 /* advance the neighbour context to the next macroblock */
-__device__ __forceinline__ void sd_next_mb(MbCtx &m, uint8_t *row, uint32_t &mbx,
-					   uint32_t W)
+__device__ __forceinline__ void sd_next_mb(MbCtx &m, uint8_t *row, uint8_t *dump,
+					   uint32_t &mbx, uint32_t W, uint32_t lane)
 {
-	if (m.row_slot >= 0)
-		row[16u * mbx + (uint32_t)m.row_slot] = (uint8_t)m.cur;
+	*lds_sel(row + 16u * mbx + (uint32_t)(m.row_slot & 15), dump,
+		 m.row_slot >= 0, lane) = (uint8_t)m.cur;
 	m.left = m.cur;
 	m.cur = 0;
 	mbx++;
@@ -674,18 +697,16 @@ sd_slice_data(WaveBits &wb, const VlcLanes &vt, uint32_t cbp_map, uint32_t lane,
 	 * row of 4x4 blocks of every component */
 	{
 		uint32_t comp = lane >> 4, b = lane & 15u;
-		int slot = -1;
-		if (lane < 48) {
-			if (comp == 0 || cat == 3)
-				slot = b == 10 ? 0 : b == 11 ? 1 : b == 14 ? 2 : b == 15 ? 3 : -1;
-			else if (cat == 1)
-				slot = b == 2 ? 0 : b == 3 ? 1 : -1;
-			else if (cat == 2)
-				slot = b == 6 ? 0 : b == 7 ? 1 : -1;
-			if (slot >= 0)
-				slot += 4 * (int)comp;
-		}
-		m.row_slot = slot;
+		/* selects only: no per-lane branches */
+		int luma_like = b == 10 ? 0 : b == 11 ? 1 : b == 14 ? 2 : b == 15 ? 3 : -1;
+		int c420 = b == 2 ? 0 : b == 3 ? 1 : -1;
+		int c422 = b == 6 ? 0 : b == 7 ? 1 : -1;
+		int slot = (comp == 0 || cat == 3) ? luma_like
+			   : cat == 1		   ? c420
+			   : cat == 2		   ? c422
+						   : -1;
+		slot = slot >= 0 ? slot + 4 * (int)comp : -1;
+		m.row_slot = lane < 48 ? slot : -1;
 	}
 	uint32_t mbx = S.first_mb % W;
 	uint32_t mbidx = 0;
@@ -704,7 +725,7 @@ sd_slice_data(WaveBits &wb, const VlcLanes &vt, uint32_t cbp_map, uint32_t lane,
 				if (mbidx >= mb_capacity)
 					return H264_AMD_E_MB_OVERFLOW;
 				sd_emit_skipped(o, skip_word0, mbidx, lane);
-				sd_next_mb(m, row, mbx, W);
+				sd_next_mb(m, row, stage - SD_DUMP_BYTES, mbx, W, lane);
 				mbidx++;
 				mb_count = mbidx;
 			}
@@ -719,11 +740,16 @@ sd_slice_data(WaveBits &wb, const VlcLanes &vt, uint32_t cbp_map, uint32_t lane,
 		/* ---- new macroblock: neighbours, clean record ---- */
 		m.availA = (mbx != 0 && mbidx >= 1) ? 1u : 0u;
 		m.availB = mbidx >= W ? 1u : 0u;
-		m.top = 0;
-		if (m.availB && m.row_slot >= 0)
-			m.top = row[16u * mbx + (uint32_t)m.row_slot];
-		for (uint32_t off = 16u * lane; off < o.rec_bytes; off += 1024u)
-			*reinterpret_cast<uint4 *>(stage + off) = make_uint4(0, 0, 0, 0);
+		{
+			uint32_t t = row[16u * mbx + (uint32_t)(m.row_slot & 15)];
+			m.top = (m.availB && m.row_slot >= 0) ? t : 0u;
+		}
+		/* clean record: the staging area is 4 KiB, zero what the
+		 * largest record (1792 B) can touch */
+		*reinterpret_cast<uint4 *>(stage + 16u * lane) = make_uint4(0, 0, 0, 0);
+		if (o.rec_bytes > 1024u)
+			*reinterpret_cast<uint4 *>(stage + 1024u + 16u * lane) =
+				make_uint4(0, 0, 0, 0);
 
 		/* ---- mb_type (ref src/h264_slice_data.c:839-969) ---- */
 		uint32_t raw_type, t, mb_type = 0, nparts = 0;
@@ -1060,11 +1086,11 @@ sd_slice_data(WaveBits &wb, const VlcLanes &vt, uint32_t cbp_map, uint32_t lane,
 			lds_w32(stage, 4, word1, lane);
 			lds_w32(stage, 8, pred_lo, lane);
 			lds_w32(stage, 12, pred_hi, lane);
-			if (lane < 48)
-				stage[16u + lane] = (uint8_t)m.cur;
+			*lds_sel(stage + 16u + lane, stage - SD_DUMP_BYTES, lane < 48,
+				 lane) = (uint8_t)m.cur;
 		}
 		sd_emit_staged(o, stage, mbidx, lane);
-		sd_next_mb(m, row, mbx, W);
+		sd_next_mb(m, row, stage - SD_DUMP_BYTES, mbx, W, lane);
 		mbidx++;
 		mb_count = mbidx;
 	} while (wb_more_rbsp_data(wb, lane));
@@ -1089,7 +1115,7 @@ struct sd_args {
 	uint32_t row_pitch; /* macroblock columns of row context in LDS */
 };
 
-extern "C" __global__ void __launch_bounds__(64)
+extern "C" __global__ void __launch_bounds__(64, 4)
 h264_amd_k_decode_slices(sd_args a)
 {
 	extern __shared__ __attribute__((aligned(16))) uint8_t lds[];
@@ -1133,8 +1159,9 @@ h264_amd_k_decode_slices(sd_args a)
 
 	/* header image starts as zeros (the reference memset()s it,
 	 * src/h264_syntax.h:1408-1410) */
-	for (uint32_t off = 16u * lane; off < SD_STAGE_BYTES; off += 1024u)
-		*reinterpret_cast<uint4 *>(stage + off) = make_uint4(0, 0, 0, 0);
+	for (uint32_t part = 0; part < SD_STAGE_BYTES / 1024u; part++)
+		*reinterpret_cast<uint4 *>(stage + part * 1024u + 16u * lane) =
+			make_uint4(0, 0, 0, 0);
 
 	WaveBits wb;
 	wb_open(wb, nal, len, ring, reinterpret_cast<uint32_t *>(lds + SD_STATE_OFF), lane);
@@ -1179,10 +1206,13 @@ h264_amd_k_decode_slices(sd_args a)
 		o.rec_bytes = sd_t2_stride(S.cat);
 		if (a.headers) {
 			uint8_t *dst = reinterpret_cast<uint8_t *>(a.headers + slice);
-			for (uint32_t off = 16u * lane;
-			     off < sizeof(struct h264_slice_header); off += 1024u)
+			const uint32_t hb = (uint32_t)sizeof(struct h264_slice_header);
+			for (uint32_t part = 0; part * 1024u < hb; part++) {
+				uint32_t want = part * 1024u + 16u * lane;
+				uint32_t off = want < hb ? want : hb - 16u;
 				*reinterpret_cast<uint4 *>(dst + off) =
 					*reinterpret_cast<const uint4 *>(stage + off);
+			}
 		}
 		if ((a.reader_flags & H264_READER_FLAGS_SLICE_DATA) && !S.entropy) {
 			if (S.unsupported) {
@@ -1205,9 +1235,9 @@ h264_amd_k_decode_slices(sd_args a)
 	/* T0: flush the partial last group of 64 words */
 	if (o.tier == H264_AMD_TIER_T0 && (mb_count & 63u) != 0) {
 		uint32_t base = mb_count & ~63u;
-		if (base + lane < mb_count)
-			*reinterpret_cast<uint32_t *>(
-				o.mb_out + (size_t)(base + lane) * o.mb_stride) = o.t0acc;
+		uint32_t l = lane < (mb_count & 63u) ? lane : (mb_count & 63u) - 1u;
+		uint32_t v = (uint32_t)__shfl((int)o.t0acc, (int)l);
+		*reinterpret_cast<uint32_t *>(o.mb_out + (size_t)(base + l) * o.mb_stride) = v;
 	}
 
 	/* wave reduction of the checksum halves */
@@ -1218,7 +1248,7 @@ h264_amd_k_decode_slices(sd_args a)
 		hi += (uint32_t)__shfl_xor((int)hi, sft);
 	}
 
-	if (lane == 0) {
+	{
 		struct h264_amd_slice_result r;
 		r.status = status;
 		r.flags = rflags;
@@ -1238,7 +1268,14 @@ h264_amd_k_decode_slices(sd_args a)
 		r.end_bit = status == 0 ? end_bit : 0u;
 		r.pic_width_in_mbs = (rflags & H264_AMD_SR_HEADER_OK) ? S.W : 0u;
 		r.checksum = ((uint64_t)hi << 32) | lo;
-		a.results[slice] = r;
+		/* every lane holds the same record: lane k stores dword k & 15 */
+		const uint32_t *src = reinterpret_cast<const uint32_t *>(&r);
+		uint32_t *dst = reinterpret_cast<uint32_t *>(a.results + slice);
+		uint32_t k = lane & 15u, v = src[0];
+#pragma unroll
+		for (uint32_t j = 1; j < 16; j++)
+			v = k == j ? src[j] : v;
+		dst[k] = v;
 	}
 }
 

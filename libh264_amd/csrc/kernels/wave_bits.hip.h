@@ -309,23 +309,25 @@ __device__ __forceinline__ void wb_open(WaveBits &s, const uint8_t *nal,
 	s.bitpos = 0;
 	s.ring = ring;
 	s.state = state;
-	if (lane < WBS_WORDS) {
-		uint32_t v = 0;
-		v = lane == WBS_ABASE_LO ? (uint32_t)ab : v;
-		v = lane == WBS_ABASE_HI ? (uint32_t)((uint64_t)ab >> 32) : v;
-		v = lane == WBS_MIS ? mis : v;
-		v = lane == WBS_LEN ? len : v;
-		v = lane == WBS_NCHUNKS ? s.nchunks : v;
-		v = lane == WBS_CARRY ? 0xffffffffu : v;
-		state[lane] = v;
+	/* branch-free (see slice_decode.hip): the 16-word state block is
+	 * written by every lane, lane k storing word k & 15 */
+	{
+		uint32_t w = lane & 15u, v = 0;
+		v = w == WBS_ABASE_LO ? (uint32_t)ab : v;
+		v = w == WBS_ABASE_HI ? (uint32_t)((uint64_t)ab >> 32) : v;
+		v = w == WBS_MIS ? mis : v;
+		v = w == WBS_LEN ? len : v;
+		v = w == WBS_NCHUNKS ? s.nchunks : v;
+		v = w == WBS_CARRY ? 0xffffffffu : v;
+		state[w] = v;
 	}
-	/* first chunk prefetch (wb_load_chunk needs the slow context) */
+	/* first chunk prefetch; lanes past the end re-read dword 0 and drop it */
 	{
 		uint32_t off = 4u * lane;
-		s.pre = 0;
-		if (off < mis + len)
-			s.pre = *reinterpret_cast<const uint32_t *>(
-				reinterpret_cast<const uint8_t *>(ab) + off);
+		bool in = off < mis + len;
+		uint32_t v = *reinterpret_cast<const uint32_t *>(
+			reinterpret_cast<const uint8_t *>(ab) + (in ? off : 0u));
+		s.pre = in ? v : 0u;
 	}
 	wb_refill(s);
 }
