@@ -231,6 +231,80 @@ class Engine:
             self.sync()
         return out
 
+    # -- slice write-back ---------------------------------------------------
+    def write_slices(self, params, d_src, out, out_capacity, sync=True):
+        """Re-serialise the slices of a decode_slices() result `out` (needs
+        want_headers=True).  Returns (d_out, offsets, sizes-as-int32 array)."""
+        n = out["n"]
+        cap = (int(out_capacity) + 15) & ~15
+        offs = np.arange(n, dtype=np.uint64) * np.uint64(cap)
+        d_offs = self.upload(offs)
+        d_sizes = self.alloc(4 * n)
+        d_out = self.alloc(n * cap)
+        a = WriteArgs()
+        a.d_src = d_src.ptr
+        a.d_descs = out["d_descs"].ptr
+        a.d_results = out["results"].ptr
+        a.d_headers = out["headers"].ptr
+        a.n = n
+        a.d_out = d_out.ptr
+        a.d_out_offsets = d_offs.ptr
+        a.d_out_sizes = d_sizes.ptr
+        a.out_capacity = cap
+        _check(engine_lib().h264_amd_write_slices(self.h, params.h,
+                                                  C.byref(a)), "write")
+        if sync:
+            self.sync()
+        sizes = self.download(d_sizes, 4 * n, dtype=np.int32)
+        return d_out, offs, sizes
+
+    # -- synthetic slices ---------------------------------------------------
+    def encode_synth(self, params, descs, headers, out_capacity):
+        """descs: list of (kind, epoch, mb_count, nal_ref_idc, nal_unit_type);
+        headers: list of SliceHeader.  Returns list of bytes (or int errno)."""
+        n = len(descs)
+        darr = (SynthDesc * n)()
+        for i, d in enumerate(descs):
+            darr[i] = SynthDesc(d[0], d[1], d[2], d[3], d[4], 0)
+        harr = (SliceHeader * n)(*headers)
+        d_descs = self.upload(np.frombuffer(bytes(darr), dtype=np.uint8))
+        d_hdrs = self.upload(np.frombuffer(bytes(harr), dtype=np.uint8))
+        cap = (int(out_capacity) + 15) & ~15
+        offs = np.arange(n, dtype=np.uint64) * np.uint64(cap)
+        d_offs = self.upload(offs)
+        d_sizes = self.alloc(4 * n)
+        d_out = self.alloc(n * cap)
+        a = SynthArgs()
+        a.d_descs = d_descs.ptr
+        a.d_headers = d_hdrs.ptr
+        a.n = n
+        a.out_capacity = cap
+        a.d_out = d_out.ptr
+        a.d_out_offsets = d_offs.ptr
+        a.d_out_sizes = d_sizes.ptr
+        _check(engine_lib().h264_amd_encode_synth_slices(
+            self.h, params.h, C.byref(a)), "synth")
+        self.sync()
+        sizes = self.download(d_sizes, 4 * n, dtype=np.int32)
+        raw = self.download(d_out, n * cap)
+        res = []
+        for i in range(n):
+            if sizes[i] < 0:
+                res.append(int(sizes[i]))
+            else:
+                res.append(raw[i * cap:i * cap + int(sizes[i])].tobytes())
+        return res
+
+    def cabac_init_states(self, triples):
+        t = np.ascontiguousarray(np.asarray(triples, dtype=np.int32))
+        n = t.shape[0]
+        d_t = self.upload(t)
+        d_s = self.alloc(n * 2048)
+        _check(engine_lib().h264_amd_cabac_init_states(self.h, d_t.ptr, n,
+                                                       d_s.ptr), "cabac_init")
+        self.sync()
+        return self.download(d_s, n * 2048).reshape(n, 1024, 2)
+
     def fetch_results(self, out):
         raw = self.download(out["results"], out["n"] * C.sizeof(SliceResult))
         return (SliceResult * out["n"]).from_buffer_copy(raw.tobytes())
