@@ -229,6 +229,13 @@ H264_API int h264_amd_params_put_sps(struct h264_amd_params *p,
 H264_API int h264_amd_params_put_pps(struct h264_amd_params *p,
 				     const struct h264_pps *pps);
 H264_API int h264_amd_params_epoch(const struct h264_amd_params *p);
+/* the SPS / PPS an id names in the current epoch (borrowed) or NULL */
+H264_API const struct h264_sps *
+h264_amd_params_sps(const struct h264_amd_params *p, uint32_t sps_id);
+H264_API const struct h264_pps *
+h264_amd_params_pps(const struct h264_amd_params *p, uint32_t pps_id);
+/* largest PicSizeInMbs over every SPS version seen: a safe mb_capacity */
+H264_API uint32_t h264_amd_params_max_mbs(const struct h264_amd_params *p);
 
 /* ---- Annex-B scan -------------------------------------------------------- */
 /* Finds every NAL unit of d_buf[0,len) with the reference's exact delimiting
@@ -269,13 +276,23 @@ struct h264_amd_write_args {
 	const struct h264_amd_slice_result *d_results; /* [n] from decode */
 	const struct h264_slice_header *d_headers; /* [n] from decode */
 	uint32_t n;
-	uint32_t reserved;
+	uint32_t wflags; /* H264_AMD_W_* */
 	uint8_t *d_out; /* output NAL bytes */
 	const uint64_t *d_out_offsets; /* [n] where each NAL goes in d_out */
 	uint32_t *d_out_sizes; /* [n] bytes written, or negative errno cast */
 	uint32_t out_capacity; /* per-NAL capacity in bytes */
 	uint32_t reserved2;
+	/* optional [n]: header length in bits as the reference's writer
+	 * records it in ctx->slice.hdr_len (src/h264_syntax.h:1380-1381).  When
+	 * a NAL ends inside a byte (no slice data given) the pending bits are
+	 * stored, left aligned, in the byte following the last whole one. */
+	uint32_t *d_out_hdr_bits;
 };
+/* wflags: bits 0-1 = number of zero bytes (0..2) that precede the output in
+ * the caller's bitstream (they take part in the 00 00 0x escape rule),
+ * bit 8 = do not insert emulation-prevention bytes */
+#define H264_AMD_W_PREV_ZEROS(n) ((n)&3u)
+#define H264_AMD_W_NO_ESCAPE 0x100u
 H264_API int h264_amd_write_slices(struct h264_amd_engine *eng,
 				   const struct h264_amd_params *params,
 				   const struct h264_amd_write_args *args);
@@ -301,6 +318,9 @@ struct h264_amd_synth_args {
 	uint8_t *d_out;
 	const uint64_t *d_out_offsets; /* [n] */
 	int32_t *d_out_sizes; /* [n] bytes written or negative errno */
+	uint32_t *d_out_hdr_bits; /* optional [n], see h264_amd_write_args */
+	uint32_t wflags; /* H264_AMD_W_* */
+	uint32_t reserved;
 };
 H264_API int h264_amd_encode_synth_slices(struct h264_amd_engine *eng,
 					  const struct h264_amd_params *params,

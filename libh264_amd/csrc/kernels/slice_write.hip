@@ -85,16 +85,20 @@ struct BitW {
 	uint32_t pos; /* bytes produced */
 	uint32_t flushed; /* bytes already in global memory (multiple of 256) */
 	uint32_t zeros; /* trailing zero OUTPUT bytes, saturating at 2 */
+	uint32_t escape; /* insert emulation-prevention bytes */
 	uint32_t overflow;
 };
 
+/* wflags: H264_AMD_W_* of <h264_amd.h> */
 __device__ __forceinline__ void bw_open(BitW &w, uint8_t *stage, uint8_t *dst,
-					uint32_t cap)
+					uint32_t cap, uint32_t wflags)
 {
 	w.stage = stage;
 	w.dst = dst;
 	w.cap = cap;
-	w.acc = w.nbits = w.pos = w.flushed = w.zeros = w.overflow = 0;
+	w.acc = w.nbits = w.pos = w.flushed = w.overflow = 0;
+	w.zeros = (wflags & 3u) > 2u ? 2u : (wflags & 3u);
+	w.escape = (wflags & H264_AMD_W_NO_ESCAPE) ? 0u : 1u;
 }
 
 /* one 256-byte row from the LDS ring to HBM; out-of-capacity lanes repeat
@@ -125,7 +129,7 @@ __device__ __forceinline__ void bw_emit(BitW &w, uint32_t byte, uint32_t lane)
 /* completed byte leaves the cache (ref src/h264_bitstream.c:54-81) */
 __device__ __forceinline__ void bw_byte(BitW &w, uint32_t byte, uint32_t lane)
 {
-	if (w.zeros >= 2 && byte <= 3) {
+	if (w.escape && w.zeros >= 2 && byte <= 3) {
 		bw_emit(w, 3, lane);
 		w.zeros = 0;
 	}
@@ -448,6 +452,8 @@ struct sw_args {
 	const uint64_t *out_offsets;
 	uint32_t *out_sizes;
 	uint32_t out_capacity;
+	uint32_t wflags;
+	uint32_t *out_hdr_bits;
 };
 
 #define SW_HDR_OFF 0u
@@ -524,18 +530,31 @@ h264_amd_k_write_slices(sw_args a)
 		status = sw_activate(P, hg(hdr, WOFF(pic_parameter_set_id)),
 				     a.spsv, a.ppsv, a.epochs + e, a.n_sps, a.n_pps);
 		BitW w;
-		bw_open(w, stage, dst, a.out_capacity);
+		bw_open(w, stage, dst, a.out_capacity, a.wflags);
 		if (status == 0)
 			status = sw_slice_header(w, hdr, P, res.nal_ref_idc,
 						 res.nal_unit_type, lane);
-		if (status == 0) {
+		if (status == 0 && a.out_hdr_bits)
+			a.out_hdr_bits[slice] = 8u * w.pos + w.nbits;
+		if (status == 0 && (res.partialbits || res.rawdata_len)) {
 			/* partial byte, then raw bytes (must be aligned now) */
 			if (res.partialbits)
 				bw_u(w, res.partial, res.partialbits, lane);
 			if (w.nbits != 0)
 				status = -EIO;
 		}
-		if (status == 0) {
+		if (status == 0 && w.nbits != 0) {
+			/* header only, ending inside a byte: hand the pending
+			 * bits back, left aligned, behind the whole bytes */
+			uint32_t pend = (w.acc << (8u - w.nbits)) & 0xffu;
+			w.stage[w.pos & (SW_STAGE_BYTES - 1)] = (uint8_t)pend;
+			w.pos++;
+			bw_drain(w, lane);
+			w.pos--;
+			if (w.overflow || w.pos + 1u > a.out_capacity)
+				status = -EIO;
+			total = w.pos;
+		} else if (status == 0) {
 			bw_drain(w, lane);
 			if (w.overflow || w.pos + res.rawdata_len > a.out_capacity ||
 			    res.rawdata_off + res.rawdata_len > d.size) {
@@ -689,6 +708,8 @@ struct synth_args {
 	const uint64_t *out_offsets;
 	int32_t *out_sizes;
 	uint32_t out_capacity;
+	uint32_t wflags;
+	uint32_t *out_hdr_bits;
 };
 
 #define SY_HDR_OFF 0u
@@ -732,7 +753,7 @@ h264_amd_k_encode_synth(synth_args a)
 	int status = 0;
 	SwParams P;
 	BitW w;
-	bw_open(w, stage, dst, a.out_capacity);
+	bw_open(w, stage, dst, a.out_capacity, a.wflags);
 	if (d.mb_count == 0 || d.kind > H264_AMD_SYNTH_SKIP_P) {
 		status = -EINVAL;
 	} else {
@@ -743,6 +764,8 @@ h264_amd_k_encode_synth(synth_args a)
 	if (status == 0)
 		status = sw_slice_header(w, hdr, P, d.nal_ref_idc, d.nal_unit_type,
 					 lane);
+	if (status == 0 && a.out_hdr_bits)
+		a.out_hdr_bits[slice] = 8u * w.pos + w.nbits;
 	if (status == 0) {
 		const uint32_t type = hg(hdr, WOFF(slice_type)) % 5u;
 		const uint32_t first_mb = hg(hdr, WOFF(first_mb_in_slice));

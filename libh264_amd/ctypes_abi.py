@@ -297,9 +297,10 @@ class DecodeArgs(S):
 class WriteArgs(S):
     _fields_ = [("d_src", C.c_void_p), ("d_descs", C.c_void_p),
                 ("d_results", C.c_void_p), ("d_headers", C.c_void_p),
-                ("n", u32), ("reserved", u32), ("d_out", C.c_void_p),
+                ("n", u32), ("wflags", u32), ("d_out", C.c_void_p),
                 ("d_out_offsets", C.c_void_p), ("d_out_sizes", C.c_void_p),
-                ("out_capacity", u32), ("reserved2", u32)]
+                ("out_capacity", u32), ("reserved2", u32),
+                ("d_out_hdr_bits", C.c_void_p)]
 
 
 class SynthDesc(S):
@@ -311,7 +312,9 @@ class SynthDesc(S):
 class SynthArgs(S):
     _fields_ = [("d_descs", C.c_void_p), ("d_headers", C.c_void_p),
                 ("n", u32), ("out_capacity", u32), ("d_out", C.c_void_p),
-                ("d_out_offsets", C.c_void_p), ("d_out_sizes", C.c_void_p)]
+                ("d_out_offsets", C.c_void_p), ("d_out_sizes", C.c_void_p),
+                ("d_out_hdr_bits", C.c_void_p), ("wflags", u32),
+                ("reserved", u32)]
 
 
 class GenCfg(S):
