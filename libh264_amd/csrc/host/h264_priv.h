@@ -83,7 +83,8 @@ struct h264_reader {
 	struct h264_amd_slice_result *h_results;
 	struct h264_slice_header *h_headers;
 	uint32_t *h_mb;
-	size_t hcap_results, hcap_headers, hcap_mb;
+	uint32_t *h_big; /* one slice that outgrew the batch's mb_capacity */
+	size_t hcap_results, hcap_headers, hcap_mb, hcap_big;
 };
 
 /* direction-agnostic syntax cursor with an error latch (paramsets.c) */

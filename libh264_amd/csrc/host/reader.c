@@ -82,6 +82,7 @@ int h264_reader_destroy(struct h264_reader *rd)
 	free(rd->h_results);
 	free(rd->h_headers);
 	free(rd->h_mb);
+	free(rd->h_big);
 	h264_ctx_destroy(rd->ctx);
 	free(rd);
 	return 0;
@@ -341,6 +342,62 @@ static int batch_fetch(struct h264_reader *rd, struct rd_batch *b, size_t idx)
 	return 0;
 }
 
+/* A damaged slice can run past the picture: the reference's macroblock table
+ * simply grows (src/h264_macroblock.c:285-316).  The batch is sized for sane
+ * pictures; a slice that overflowed it is decoded again on its own with 8x
+ * the room until it fits.  RD_MAX_MB_CAP bounds what a corrupt mb_skip_run can
+ * ask for (the reference would call back 2^32 times); beyond it the slice
+ * fails with -EOVERFLOW. */
+#define RD_MAX_MB_CAP (1u << 22)
+
+static int retry_big_slice(struct h264_reader *rd, struct rd_batch *b,
+			   size_t slice, struct h264_amd_slice_result *r,
+			   const uint32_t **t0)
+{
+	struct h264_amd_decode_args a;
+	uint32_t cap = b->mb_cap;
+	int res;
+	do {
+		size_t mb_bytes;
+		cap = cap > RD_MAX_MB_CAP / 8 ? RD_MAX_MB_CAP : cap * 8;
+		mb_bytes = b->tier == H264_AMD_TIER_T0 ? (size_t)cap * 4 : 0;
+		if (mb_bytes) {
+			res = h264_host_grow(&rd->d_mb, &rd->cap_mb, mb_bytes);
+			if (res < 0)
+				return res;
+		}
+		memset(&a, 0, sizeof(a));
+		a.d_buf = rd->d_buf;
+		a.d_descs = (const struct h264_amd_slice_desc *)rd->d_descs + slice;
+		a.n = 1;
+		a.reader_flags = b->flags;
+		a.tier = b->tier;
+		a.mb_capacity = cap;
+		a.d_results = rd->d_results;
+		a.d_headers = rd->d_headers;
+		a.d_mb_out = mb_bytes ? rd->d_mb : NULL;
+		a.mb_stride = mb_bytes ? 4 : 0;
+		res = h264_amd_decode_slices(b->eng, rd->params, &a);
+		if (res == 0)
+			res = h264_amd_download(b->eng, r, rd->d_results,
+						sizeof(*r));
+		if (res < 0)
+			return res;
+	} while (r->status == H264_AMD_E_MB_OVERFLOW && cap < RD_MAX_MB_CAP);
+	*t0 = NULL;
+	if (b->tier == H264_AMD_TIER_T0 && r->mb_count > 0) {
+		size_t bytes = (size_t)r->mb_count * 4;
+		res = host_grow((void **)&rd->h_big, &rd->hcap_big, bytes);
+		if (res == 0)
+			res = h264_amd_download(b->eng, rd->h_big, rd->d_mb,
+						bytes);
+		if (res < 0)
+			return res;
+		*t0 = rd->h_big;
+	}
+	return 0;
+}
+
 /* ---- step 4: replay -------------------------------------------------------- */
 
 static int replay_slice(struct h264_reader *rd, const uint8_t *nal, size_t len,
@@ -420,6 +477,9 @@ static int replay_nal(struct h264_reader *rd, struct rd_batch *b,
 	switch (t) {
 	case H264_NALU_TYPE_SLICE:
 	case H264_NALU_TYPE_SLICE_IDR: {
+		const struct h264_amd_slice_result *r;
+		struct h264_amd_slice_result big;
+		const uint32_t *t0;
 		size_t k;
 		if (slice < 0 || b == NULL)
 			return -EPROTO;
@@ -427,11 +487,16 @@ static int replay_nal(struct h264_reader *rd, struct rd_batch *b,
 		if (res < 0)
 			return res;
 		k = (size_t)slice - b->lo;
-		res = replay_slice(rd, nal, len, &rd->h_results[k],
-				   &rd->h_headers[k],
-				   b->tier == H264_AMD_TIER_T0
-					   ? rd->h_mb + k * b->mb_cap
-					   : NULL);
+		r = &rd->h_results[k];
+		t0 = b->tier == H264_AMD_TIER_T0 ? rd->h_mb + k * b->mb_cap
+						 : NULL;
+		if (r->status == H264_AMD_E_MB_OVERFLOW) {
+			res = retry_big_slice(rd, b, (size_t)slice, &big, &t0);
+			if (res < 0)
+				return res;
+			r = &big;
+		}
+		res = replay_slice(rd, nal, len, r, &rd->h_headers[k], t0);
 		if (res < 0)
 			return res;
 		if (cbs->slice)

@@ -375,3 +375,24 @@ int orc_bs_write_raw_bytes(struct h264_bitstream *bs, const uint8_t *buf,
 	bs->off += len;
 	return 0;
 }
+
+/* Same contract as ref_bs_read_script() of ref_harness/ref_bits.c, on the
+ * oracle's reader: lets tests/test_oracle_pins.py compare long read sequences
+ * with the reference's inline reader. */
+int orc_bs_read_script(const uint8_t *buf, size_t len, int ep,
+		       const uint8_t *counts, size_t n, uint32_t *out,
+		       uint64_t *pos)
+{
+	struct h264_bitstream bs;
+	size_t i;
+	h264_bs_cinit(&bs, buf, len, ep);
+	for (i = 0; i < n; i++) {
+		uint32_t v = 0;
+		int res = orc_bs_read_bits(&bs, &v, counts[i]);
+		out[i] = res < 0 ? 0xFFFFFFFFu : v;
+		pos[i] = ((uint64_t)bs.off << 8) | bs.cachebits;
+		if (res < 0)
+			return (int)i;
+	}
+	return (int)n;
+}

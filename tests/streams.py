@@ -72,3 +72,47 @@ def annexb(nals, long_codes=None):
         out += b"\x00\x00\x00\x01" if four else b"\x00\x00\x01"
         out += bytes(n)
     return bytes(out)
+
+
+def mixed_nals(cfg, n_slices=24, seed0=0, split=True):
+    """SPS, PPS, then pictures made of AUD + SEI + one or two slices, with a
+    filler now and then and a repeated parameter-set pair in the middle."""
+    nals = [gen.sps(cfg), gen.pps(cfg)]
+    total = cfg.width_mbs * cfg.height_mbs
+    for k in range(n_slices):
+        seed = seed0 + k
+        st = (2, 0, 1, 0)[k % 4]
+        if k % 3 == 0:
+            nals.append(gen.aud(k % 3))
+        if k % 5 == 0:
+            nals.append(gen.sei_user_data(40 + k, seed + 1))
+        if split and k % 2:
+            half = total // 2
+            nals.append(gen.slice_nal(
+                cfg, rich_slice(cfg, seed, st, 0, half)))
+            nals.append(gen.slice_nal(
+                cfg, rich_slice(cfg, seed, st, half, total - half)))
+        else:
+            nals.append(gen.slice_nal(cfg, rich_slice(cfg, seed, st)))
+        if k % 7 == 3:
+            nals.append(gen.filler(20 + k))
+        if k == n_slices // 2:
+            nals += [gen.sps(cfg), gen.pps(cfg)]
+    return nals
+
+
+def damage(nals, seed, first=2):
+    """Truncate / bit-flip / forbid some NAL units, deterministically."""
+    import random
+    rnd = random.Random(seed)
+    out = [bytearray(n) for n in nals]
+    for i in range(first, len(out)):
+        r = rnd.random()
+        if r < 0.15 and len(out[i]) > 8:
+            del out[i][rnd.randrange(4, len(out[i])):]
+        elif r < 0.30 and len(out[i]) > 8:
+            p = rnd.randrange(1, len(out[i]))
+            out[i][p] ^= 1 << rnd.randrange(8)
+        elif r < 0.34:
+            out[i][0] |= 0x80
+    return [bytes(n) for n in out]
