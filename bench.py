@@ -78,7 +78,7 @@ def main():
     n_gpus = world
 
     import libh264_amd
-    from libh264_amd import gen, Params
+    from libh264_amd import gen, Params, shard
     from libh264_amd.ctypes_abi import Sps, Pps, TIER_NONE, TIER_T0, TIER_T1
 
     # a GPU box gives each GPU a share of 16 host cores whatever os.cpu_count()
@@ -90,7 +90,7 @@ def main():
     cores = max(1, min(avail, int(os.environ.get("H264_AMD_HOST_CORES", "16"))))
     threads = cores
     t0 = time.time()
-    cfg, buf, offs, sizes = make_workload(args.slices, 1000003 * rank + 17,
+    cfg, buf, offs, sizes = make_workload(args.slices, shard.rank_seed(rank),
                                           threads)
     gen_s = time.time() - t0
     total_bytes = int(sizes.sum())
@@ -119,7 +119,7 @@ def main():
     epoch = params.put_pps(pps)
 
     # largest slices first: the last wavefronts to start are the shortest
-    order = np.argsort(-sizes.astype(np.int64), kind="stable")
+    order = shard.longest_first(sizes)
     descs = np.zeros(args.slices, dtype=[("offset", "<u8"), ("size", "<u4"),
                                          ("epoch", "<u4")])
     descs["offset"] = offs[order]
@@ -151,11 +151,7 @@ def main():
         kernel_ms.append(eng.last_kernel_ms("decode"))
     barrier()
     elapsed = time.perf_counter() - t_start
-    if dist is not None:
-        import torch
-        t = torch.tensor([elapsed], device="cuda")
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        elapsed = float(t.item())
+    elapsed = shard.max_over_ranks(dist, elapsed, device="cuda")
 
     res = eng.fetch_results(out)
     bad = [i for i in range(args.slices)
@@ -186,7 +182,9 @@ def main():
                 raise SystemExit("parity failure on slice %d" % i)
             verified += 1
         if world == 1:
-            n_s = args.cpu_sample or min(args.slices, cores * 24)
+            # ~1 M macroblocks/s per core: 128 slices per core is 15-20 s
+            # of CPU work, about a second of wall time on the box's share
+            n_s = args.cpu_sample or min(args.slices, cores * 128)
             sel = np.arange(n_s)
             o = np.ascontiguousarray(offs[sel])
             z = np.ascontiguousarray(sizes[sel])
@@ -210,18 +208,31 @@ def main():
             }
 
     ms_per_step = 1e3 * elapsed / args.steps
-    if dist is not None:
-        import torch
-        tb = torch.tensor([float(total_bytes), float(total_mbs)],
-                          device="cuda", dtype=torch.float64)
-        dist.all_reduce(tb)
-        all_bytes, all_mbs = float(tb[0].item()), float(tb[1].item())
-    else:
-        all_bytes, all_mbs = float(total_bytes), float(total_mbs)
+    all_bytes, all_mbs = shard.sum_over_ranks(dist, [total_bytes, total_mbs],
+                                              device="cuda")
     mbit_s = 8.0 * all_bytes * args.steps / elapsed / 1e6
     k_ms = float(np.mean(kernel_ms))
     achieved = total_bytes / (k_ms * 1e-3) / 1e9
     out_bytes = args.slices * (64 + 8160 * out["stride"])
+
+    # HBM traffic per launch comes from PMC passes of this very command
+    # (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, one counter per pass; a
+    # profiler cannot run inside the timed process).  The summary is committed
+    # under profiles/ and only used when it was taken on the identical
+    # workload (same seeded bytes, slice count and tier).
+    traffic, traffic_src = None, None
+    try:
+        import glob
+        for f in sorted(glob.glob(os.path.join(ROOT, "profiles",
+                                               "r*_decode_hbm_traffic.json"))):
+            t = json.load(open(f))
+            if (t.get("bytes_per_gpu") == total_bytes and
+                    t.get("slices") == args.slices and
+                    t.get("tier") == ["none", "T0", "T1"][args.tier]):
+                traffic = t["hbm_bytes_per_launch"]
+                traffic_src = os.path.relpath(f, ROOT)
+    except (OSError, ValueError, KeyError):
+        traffic = None
 
     if rank == 0:
         line = {
@@ -256,7 +267,8 @@ def main():
                 "peak": HBM_PEAK_GBS,
                 "unit": "GB/s",
                 "frac": round(achieved / HBM_PEAK_GBS, 5),
-                "traffic": None,
+                "traffic": traffic,
+                "traffic_source": traffic_src,
                 "kernel_ms": round(k_ms, 3),
                 "algorithmic_bytes_read": total_bytes,
                 "algorithmic_bytes_written": out_bytes,
