@@ -440,12 +440,26 @@ sd_slice_header(WaveBits &wb, uint32_t lane, uint8_t *stage, SliceState &S,
 
 /* ---- macroblock bookkeeping ---------------------------------------------- */
 
+/* Neighbour context of 9.2.1 (nC) kept incrementally.  Lane l = comp * 16 +
+ * blkIdx stands for one 4x4 block.  `sum` holds nA + nB of that block as far as
+ * they are known: the external (left / above macroblock) part is loaded when
+ * the macroblock starts, the internal part is added when the neighbouring
+ * block of the same macroblock has been decoded.  Reading nC is then one
+ * v_readlane instead of the index arithmetic of
+ * src/h264_slice_data.c:1319-1334. */
 struct MbCtx {
-	/* per lane: nz_coeff of the current / left / above macroblock, lane =
-	 * comp * 16 + blkIdx (above: only its bottom row is populated) */
-	uint32_t cur, left, top;
-	int row_slot; /* per lane: byte of the row context this lane owns */
+	/* per lane, changing */
+	uint32_t cur; /* nz_coeff of the current macroblock */
+	uint32_t left; /* nz_coeff of the previous macroblock */
+	uint32_t sum; /* nA + nB of this lane's block */
+	/* per lane, constant for the slice */
+	uint32_t a_int, b_int; /* lane of the A / B neighbour inside the MB or 0xff */
+	uint32_t a_ext; /* lane (previous MB) of an external A neighbour or 0xff */
+	int top_slot; /* row-context byte holding an external B neighbour or -1 */
+	int row_slot; /* row-context byte this lane saves (bottom row) or -1 */
+	uint32_t info_n, info_i16; /* lane = residual step: block parameters */
 	/* uniform */
+	uint64_t both; /* lanes with both neighbours available */
 	uint32_t availA, availB;
 };
 
@@ -455,81 +469,155 @@ __device__ __forceinline__ uint32_t blk_at(uint32_t x, uint32_t y)
 	return (x & 1u) | ((y & 1u) << 1) | ((x >> 1) << 2) | ((y >> 1) << 3);
 }
 
-/* nC of 9.2.1 as the reference computes it (src/h264_slice_data.c:1319-1334) */
-__device__ __forceinline__ uint32_t sd_nc(const MbCtx &m, uint32_t comp,
-					  uint32_t blk, uint32_t chroma,
-					  uint32_t cat)
+#define SD_INFO(nzlane, maxnum, cdc, coef)                                     \
+	((nzlane) | ((maxnum) << 6) | ((cdc) << 11) | ((coef) << 13))
+
+/* Per-lane constants: neighbour geometry (6.4.11.4, as restated by the
+ * reference in src/h264_slice_data.c:1239-1334) and, with lane = step, the
+ * parameters of every residual block in bitstream order
+ * (src/h264_syntax_slice_data.h:334-419): for each luma-like component the
+ * Intra16x16 DC block then its 16 4x4 blocks, then chroma DC Cb, Cr, chroma AC
+ * Cb, Cr. */
+__device__ __forceinline__ void sd_mb_consts(MbCtx &m, uint32_t lane, uint32_t cat)
 {
-	uint32_t x, y, lA, lB, w4, h4;
-	if (chroma) {
-		x = blk & 1u;
-		y = blk >> 1;
-		w4 = 2;
-		h4 = cat == 1 ? 2u : 4u;
-		lA = x ? 2u * y + x - 1u : 2u * y + w4 - 1u;
-		lB = y ? 2u * (y - 1u) + x : 2u * (h4 - 1u) + x;
-	} else {
-		x = (blk & 1u) | ((blk >> 1) & 2u);
-		y = ((blk >> 1) & 1u) | ((blk >> 2) & 2u);
-		lA = blk_at(x ? x - 1u : 3u, y);
-		lB = blk_at(x, y ? y - 1u : 3u);
+	const uint32_t comp = lane >> 4, b = lane & 15u;
+	const bool lumalike = lane < 48 && (comp == 0 || cat == 3);
+	const bool chroma = lane < 48 && comp > 0 && (cat == 1 || cat == 2);
+	const uint32_t nchroma = cat == 1 ? 4u : 8u, h4 = cat == 1 ? 2u : 4u;
+	/* luma geometry */
+	const uint32_t lx = (b & 1u) | ((b >> 1) & 2u);
+	const uint32_t ly = ((b >> 1) & 1u) | ((b >> 2) & 2u);
+	/* chroma geometry: 2 blocks wide */
+	const uint32_t cx = b & 1u, cy = b >> 1;
+	const bool cvalid = chroma && b < nchroma;
+
+	uint32_t a_int = 0xff, b_int = 0xff, a_ext = 0xff;
+	int top_slot = -1, row_slot = -1;
+	if (lumalike) {
+		a_int = lx ? 16u * comp + blk_at(lx - 1u, ly) : 0xffu;
+		a_ext = lx ? 0xffu : 16u * comp + blk_at(3, ly);
+		b_int = ly ? 16u * comp + blk_at(lx, ly - 1u) : 0xffu;
+		top_slot = ly ? -1 : (int)(4u * comp + lx);
+		row_slot = ly == 3 ? (int)(4u * comp + lx) : -1;
 	}
-	lA += 16u * comp;
-	lB += 16u * comp;
-	uint32_t availA = x ? 1u : m.availA, availB = y ? 1u : m.availB;
-	uint32_t nA = (uint32_t)__builtin_amdgcn_readlane(
-		(int)(x ? m.cur : m.left), (int)lA);
-	uint32_t nB = (uint32_t)__builtin_amdgcn_readlane(
-		(int)(y ? m.cur : m.top), (int)lB);
-	if (availA && availB)
-		return (nA + nB + 1u) >> 1;
-	if (availA)
-		return nA;
-	if (availB)
-		return nB;
-	return 0;
+	if (cvalid) {
+		a_int = cx ? 16u * comp + 2u * cy : 0xffu;
+		a_ext = cx ? 0xffu : 16u * comp + 2u * cy + 1u;
+		b_int = cy ? 16u * comp + 2u * (cy - 1u) + cx : 0xffu;
+		top_slot = cy ? -1 : (int)(4u * comp + cx);
+		row_slot = cy == h4 - 1u ? (int)(4u * comp + cx) : -1;
+	}
+	m.a_int = a_int;
+	m.b_int = b_int;
+	m.a_ext = a_ext;
+	m.top_slot = top_slot;
+	m.row_slot = row_slot;
+
+	/* residual steps */
+	const uint32_t luma_steps = 17u * (cat == 3 ? 3u : 1u);
+	const uint32_t s = lane;
+	uint32_t in = 0, ii = 0;
+	if (s < luma_steps) {
+		uint32_t c = s / 17u, sub = s % 17u;
+		if (sub == 0) {
+			in = ii = SD_INFO(16u * c, 16u, 0u, 256u * c);
+		} else {
+			uint32_t blk = sub - 1u;
+			in = SD_INFO(16u * c + blk, 16u, 0u, 256u * c + 16u * blk);
+			ii = SD_INFO(16u * c + blk, 15u, 0u,
+				     256u * c + 16u + 15u * blk);
+		}
+	} else if (cat == 1 || cat == 2) {
+		uint32_t c = s - luma_steps;
+		if (c < 2) {
+			in = SD_INFO(16u * (1u + c), nchroma, cat, 256u + nchroma * c);
+		} else if (c < 2u + 2u * nchroma) {
+			c -= 2u;
+			uint32_t cc = c >= nchroma ? 1u : 0u;
+			uint32_t blk = c - cc * nchroma;
+			in = SD_INFO(16u * (1u + cc) + blk, 15u, 0u,
+				     256u + 2u * nchroma + 15u * (nchroma * cc + blk));
+		}
+		ii = in;
+	}
+	m.info_n = in;
+	m.info_i16 = ii;
+}
+
+/* A macroblock starts: external neighbour sums and the both-available mask */
+__device__ __forceinline__ void sd_mb_begin(MbCtx &m, const uint8_t *row,
+					    uint32_t mbx, uint32_t lane)
+{
+	uint32_t lv = (uint32_t)__shfl((int)m.left, (int)(m.a_ext & 63u));
+	uint32_t tv = row[16u * mbx + (uint32_t)(m.top_slot & 15)];
+	bool extA = m.a_ext != 0xffu && m.availA != 0;
+	bool extB = m.top_slot >= 0 && m.availB != 0;
+	m.sum = (extA ? lv : 0u) + (extB ? tv : 0u);
+	bool hasA = m.a_int != 0xffu || extA;
+	bool hasB = m.b_int != 0xffu || extB;
+	m.both = __ballot(hasA && hasB);
+}
+
+/* nC of the block at lane l (9.2.1): (nA + nB + 1) >> 1 with both neighbours,
+ * the available one alone otherwise, 0 with none */
+__device__ __forceinline__ uint32_t sd_nc(const MbCtx &m, uint32_t l)
+{
+	uint32_t s = (uint32_t)__builtin_amdgcn_readlane((int)m.sum, (int)l);
+	uint32_t bb = (uint32_t)(m.both >> l) & 1u;
+	return (s + bb) >> bb;
+}
+
+/* block at lane l now has TotalCoeff tc (it may have had another value: the
+ * DC blocks park theirs at index 0, Appendix C.4) */
+__device__ __forceinline__ void sd_nz_set(MbCtx &m, uint32_t l, uint32_t tc,
+					  uint32_t lane)
+{
+	uint32_t old = (uint32_t)__builtin_amdgcn_readlane((int)m.cur, (int)l);
+	if (tc != old) {
+		uint32_t delta = tc - old;
+		m.cur = lane == l ? tc : m.cur;
+		m.sum += (m.a_int == l ? delta : 0u) + (m.b_int == l ? delta : 0u);
+	}
 }
 
 /* 9.2 residual_block (ref src/h264_syntax_slice_data.h:103-242).  The decoded
  * levels go to stage[coef_off ...] (int16 units from the record start).
- * Returns 0 or -EIO; tc_out = TotalCoeff. */
-__device__ __forceinline__ int sd_residual_block(WaveBits &wb, const VlcLanes &vt,
-						 uint32_t lane, uint8_t *stage,
-						 uint32_t nC, uint32_t chroma_dc,
-						 uint32_t maxnum, uint32_t coef_off,
-						 uint32_t &tc_out)
+ * Returns an error flag (non-zero: the slice ends with -EIO); tc_out =
+ * TotalCoeff.  Malformed codes do not branch out: they raise the flag and the
+ * walk goes on with benign values until the caller looks at it. */
+__device__ __forceinline__ uint32_t sd_residual_block(WaveBits &wb, const VlcLanes &vt,
+						      uint32_t lane, uint8_t *stage,
+						      uint32_t nC, uint32_t chroma_dc,
+						      uint32_t maxnum, uint32_t coef_off,
+						      uint32_t &tc_out)
 {
 	uint32_t t1, tc;
-	if (!vlc_coeff_token(vt, wb, lane, nC, chroma_dc, t1, tc))
-		return -EIO;
+	uint32_t err = vlc_coeff_token(vt, wb, lane, nC, chroma_dc, t1, tc);
 	tc_out = tc;
 	if (tc == 0)
-		return 0;
+		return err;
 	uint32_t lv = 0; /* per lane: level i */
 	uint32_t zl = 0; /* per lane: zerosLeft before run i */
 	uint32_t suffix_len = (tc > 10 && t1 < 3) ? 1u : 0u;
 	uint32_t i = 0;
 	if (t1) {
+		/* trailing ones: bit (t1 - 1 - i) of the sign field is level i */
 		uint32_t signs = wb_u(wb, lane, t1);
-		for (; i < t1; i++) {
-			uint32_t neg = (signs >> (t1 - 1u - i)) & 1u;
-			lv = wb_setlane(lv, i, neg ? 0xffffu : 1u, lane);
-		}
+		uint32_t sbit = (signs >> ((t1 - 1u - lane) & 31u)) & 1u;
+		lv = lane < t1 ? (sbit ? 0xffffu : 1u) : 0u;
+		i = t1;
 	}
 	for (; i < tc; i++) {
 		uint32_t bits = wb_peek(wb, lane);
-		if (bits < (1u << 6))
-			return -EIO; /* level_prefix > 25 */
-		uint32_t prefix = (uint32_t)__builtin_clz(bits);
+		err |= bits < (1u << 6) ? 1u : 0u; /* level_prefix > 25 */
+		uint32_t prefix = (uint32_t)__builtin_clz(bits | 0x3fu);
 		wb_skip(wb, prefix + 1u);
 		uint32_t code = (prefix < 15u ? prefix : 15u) << suffix_len;
-		if (suffix_len > 0 || prefix >= 14) {
-			uint32_t size = (prefix == 14 && suffix_len == 0) ? 4u
-					: prefix >= 15		  ? prefix - 3u
-								  : suffix_len;
-			if (size)
-				code += wb_u(wb, lane, size);
-		}
+		uint32_t size = (prefix == 14 && suffix_len == 0) ? 4u
+				: prefix >= 15		  ? prefix - 3u
+							  : suffix_len;
+		if (size)
+			code += wb_u(wb, lane, size);
 		if (prefix >= 15 && suffix_len == 0)
 			code += 15;
 		if (prefix >= 16)
@@ -547,29 +635,27 @@ __device__ __forceinline__ int sd_residual_block(WaveBits &wb, const VlcLanes &v
 			suffix_len++;
 	}
 	uint32_t zeros_left = 0;
-	if (tc < maxnum) {
-		if (!vlc_total_zeros(vt, wb, lane, tc, maxnum, zeros_left))
-			return -EIO;
-	}
+	if (tc < maxnum)
+		err |= vlc_total_zeros(vt, wb, lane, tc, maxnum, zeros_left);
 	for (i = 0; i + 1 < tc && zeros_left > 0; i++) {
 		uint32_t run;
 		zl = wb_setlane(zl, i, zeros_left, lane);
-		if (!vlc_run_before(vt, wb, lane, zeros_left, run))
-			return -EIO;
-		if (run > zeros_left)
-			return -EIO;
-		zeros_left -= run;
+		err |= vlc_run_before(vt, wb, lane, zeros_left, run);
+		uint32_t over = run > zeros_left ? 1u : 0u;
+		err |= over;
+		zeros_left -= over ? zeros_left : run;
 	}
 	zl = wb_setlane(zl, tc - 1u, zeros_left, lane);
 	/* lane i places coefficient i */
 	uint32_t pos = zl + tc - 1u - lane;
 	bool mine = lane < tc;
-	if (__ballot(mine && pos >= maxnum))
-		return -EIO; /* malformed: outside the block (Appendix C.5) */
+	/* malformed: outside the block (Appendix C.5) */
+	bool outside = mine && pos >= maxnum;
+	err |= __ballot(outside) != 0 ? 1u : 0u;
 	*reinterpret_cast<uint16_t *>(
 		lds_sel(stage + H264_AMD_T2_HEAD + 2u * (coef_off + pos),
-			stage - SD_DUMP_BYTES, mine, lane)) = (uint16_t)lv;
-	return 0;
+			stage - SD_DUMP_BYTES, mine && !outside, lane)) = (uint16_t)lv;
+	return err;
 }
 
 /* checksum terms of 8 consecutive 16-bit words starting at word index idx */
@@ -691,23 +777,10 @@ sd_slice_data(WaveBits &wb, const VlcLanes &vt, uint32_t cbp_map, uint32_t lane,
 	const uint32_t nchroma = cat == 1 ? 4u : 8u; /* 4x4 blocks per component */
 	bool ok = true;
 	MbCtx m;
-	m.cur = m.left = m.top = 0;
+	m.cur = m.left = m.sum = 0;
 	m.availA = m.availB = 0;
-	/* which byte of the per-column row context this lane saves: the bottom
-	 * row of 4x4 blocks of every component */
-	{
-		uint32_t comp = lane >> 4, b = lane & 15u;
-		/* selects only: no per-lane branches */
-		int luma_like = b == 10 ? 0 : b == 11 ? 1 : b == 14 ? 2 : b == 15 ? 3 : -1;
-		int c420 = b == 2 ? 0 : b == 3 ? 1 : -1;
-		int c422 = b == 6 ? 0 : b == 7 ? 1 : -1;
-		int slot = (comp == 0 || cat == 3) ? luma_like
-			   : cat == 1		   ? c420
-			   : cat == 2		   ? c422
-						   : -1;
-		slot = slot >= 0 ? slot + 4 * (int)comp : -1;
-		m.row_slot = lane < 48 ? slot : -1;
-	}
+	m.both = 0;
+	sd_mb_consts(m, lane, cat);
 	uint32_t mbx = S.first_mb % W;
 	uint32_t mbidx = 0;
 	const uint32_t skip_word0 =
@@ -740,10 +813,7 @@ sd_slice_data(WaveBits &wb, const VlcLanes &vt, uint32_t cbp_map, uint32_t lane,
 		/* ---- new macroblock: neighbours, clean record ---- */
 		m.availA = (mbx != 0 && mbidx >= 1) ? 1u : 0u;
 		m.availB = mbidx >= W ? 1u : 0u;
-		{
-			uint32_t t = row[16u * mbx + (uint32_t)(m.row_slot & 15)];
-			m.top = (m.availB && m.row_slot >= 0) ? t : 0u;
-		}
+		sd_mb_begin(m, row, mbx, lane);
 		/* clean record: the staging area is 4 KiB, zero what the
 		 * largest record (1792 B) can touch */
 		*reinterpret_cast<uint4 *>(stage + 16u * lane) = make_uint4(0, 0, 0, 0);
@@ -1004,73 +1074,48 @@ sd_slice_data(WaveBits &wb, const VlcLanes &vt, uint32_t cbp_map, uint32_t lane,
 			}
 			if (cbp_luma > 0 || cbp_chroma > 0 || pm0 == PM_I16x16) {
 				RD_SE(qpd);
-				/* ---- residual (:334-419): one loop over every
-				 * 4x4 block so that residual_block exists once ---- */
+				/* ---- residual (:334-419).  The coded blocks
+				 * are the set bits of `todo` (bit = step, in
+				 * bitstream order); blocks that are not coded cost
+				 * nothing ---- */
 				const bool i16 = pm0 == PM_I16x16;
-				const uint32_t luma_steps = 17u * (cat == 3 ? 3u : 1u);
-				const uint32_t steps =
-					luma_steps + (chroma12 ? 2u + 2u * nchroma : 0u);
-				uint32_t comp = 0, sub = 0; /* sub-step inside a comp */
-				for (uint32_t step = 0; step < steps; step++) {
-					uint32_t blk, maxnum, coef_off, nzlane;
-					uint32_t chroma_dc = 0, nC = 0;
-					bool coded;
-					if (step < luma_steps) {
-						if (sub == 0) {
-							/* Intra16x16 DC */
-							coded = i16;
-							blk = 0;
-							maxnum = 16;
-							coef_off = 256u * comp;
-						} else {
-							blk = sub - 1u;
-							coded = (cbp_luma >> (blk >> 2)) & 1u;
-							maxnum = i16 ? 15u : 16u;
-							coef_off = 256u * comp +
-								   (i16 ? 16u + 15u * blk : 16u * blk);
-						}
-						nzlane = 16u * comp + blk;
-						if (coded)
-							nC = sd_nc(m, comp, blk, 0, cat);
-						if (++sub == 17u) {
-							sub = 0;
-							comp++;
-						}
-					} else {
-						uint32_t c = step - luma_steps;
-						if (c < 2) {
-							coded = (cbp_chroma & 3u) != 0;
-							chroma_dc = cat; /* 1 or 2 */
-							maxnum = nchroma;
-							coef_off = 256u + nchroma * c;
-							blk = 0;
-							nzlane = 16u * (1u + c);
-						} else {
-							c -= 2;
-							uint32_t cc = c >= nchroma ? 1u : 0u;
-							blk = c - cc * nchroma;
-							coded = (cbp_chroma & 2u) != 0;
-							maxnum = 15;
-							coef_off = 256u + 2u * nchroma +
-								   15u * (nchroma * cc + blk);
-							nzlane = 16u * (1u + cc) + blk;
-							if (coded)
-								nC = sd_nc(m, 1u + cc, blk, 1, cat);
-						}
-					}
-					if (!coded)
-						continue;
-					wb_sync(wb, lane);
+				const uint32_t ncomp = cat == 3 ? 3u : 1u;
+				/* cbp_luma bit k covers blocks 4k..4k+3 */
+				uint32_t e16 = ((cbp_luma & 1u) | ((cbp_luma & 2u) << 3) |
+						((cbp_luma & 4u) << 6) |
+						((cbp_luma & 8u) << 9)) * 15u;
+				uint64_t per_comp = ((uint64_t)e16 << 1) | (i16 ? 1u : 0u);
+				uint64_t todo = per_comp;
+				if (ncomp == 3)
+					todo |= (per_comp << 17) | (per_comp << 34);
+				if (chroma12) {
+					uint64_t c = 0;
+					if (cbp_chroma & 3u)
+						c |= 3u;
+					if (cbp_chroma & 2u)
+						c |= ((1ull << (2u * nchroma)) - 1ull) << 2;
+					todo |= c << 17;
+				}
+				const uint32_t vinfo = i16 ? m.info_i16 : m.info_n;
+				uint32_t err = 0;
+				while (todo) {
+					uint32_t step = (uint32_t)__builtin_ctzll(todo);
+					todo &= todo - 1ull;
+					uint32_t info = (uint32_t)__builtin_amdgcn_readlane(
+						(int)vinfo, (int)step);
+					uint32_t nzlane = info & 63u;
 					uint32_t tc;
-					int r = sd_residual_block(wb, vt, lane, stage, nC,
-								  chroma_dc, maxnum,
-								  coef_off, tc);
-					if (r)
-						return r;
+					wb_sync(wb, lane);
+					err |= sd_residual_block(
+						wb, vt, lane, stage, sd_nc(m, nzlane),
+						(info >> 11) & 3u, (info >> 6) & 31u,
+						info >> 13, tc);
 					/* TotalCoeff is recorded for every class, DC
 					 * blocks included (Appendix C.4) */
-					m.cur = wb_setlane(m.cur, nzlane, tc, lane);
+					sd_nz_set(m, nzlane, tc, lane);
 				}
+				if (err)
+					return -EIO;
 			}
 		}
 		if (wb_overrun(wb))

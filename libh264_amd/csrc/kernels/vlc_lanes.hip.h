@@ -39,16 +39,37 @@ __device__ __forceinline__ void vlc_load(VlcLanes &t, const dev_vlc_tables *src,
 					 uint32_t lane)
 {
 #pragma unroll
-	for (int i = 0; i < VLC_ROWS; i++)
+	for (int i = 0; i < 20; i++)
 		t.r[i] = src->e[i][lane];
+	/* run_before, zerosLeft 1..6: entry = len << 4 | run for each value of
+	 * the next 3 bits, 8 entries packed into the 64-bit word of lane
+	 * zerosLeft (Table 9-10):
+	 *  1: 1 0            2: 1 01 00          3: 11 10 01 00
+	 *  4: 11 10 01 001 000                   5: 11 10 011 010 001 000
+	 *  6: 11 000 001 011 010 101 100 (runs 0..6) */
+	uint64_t tb = lane == 1   ? 0x1010101011111111ull
+		      : lane == 2 ? 0x1010101021212222ull
+		      : lane == 3 ? 0x2020212122222323ull
+		      : lane == 4 ? 0x2020212122223334ull
+		      : lane == 5 ? 0x2020212132333435ull
+		      : lane == 6 ? 0x2020353633343231ull
+				  : 0ull;
+	t.r[20] = (uint32_t)tb;
+	t.r[21] = (uint32_t)(tb >> 32);
 }
 
-/* first lane inside `group` whose code word prefixes `bits`; -1 if none */
+/* Decoders below never branch on a malformed code word: they return a "bad"
+ * flag (0 / 1) for the caller to OR into its error word and hand back benign
+ * values, so that the parse loop carries plain 32-bit integers instead of
+ * booleans (which the backend would keep as 64-bit lane masks). */
+
+/* first lane inside `group` whose code word prefixes `bits`; -1 if none
+ * (s_ff1_i32_b64 of zero) */
 __device__ __forceinline__ int vlc_find(uint32_t mask, uint32_t code,
 					uint32_t bits, wb_mask_t group)
 {
 	wb_mask_t m = __ballot((bits & mask) == code) & group;
-	return m ? (int)__builtin_ctzll(m) : -1;
+	return __builtin_ffsll((long long)m) - 1;
 }
 
 __device__ __forceinline__ uint32_t vlc_len(uint32_t mask_row, int lane_hit)
@@ -62,138 +83,120 @@ __device__ __forceinline__ wb_mask_t vlc_group(uint32_t base, uint32_t n)
 	return ((1ull << n) - 1ull) << base;
 }
 
-/* coeff_token for the tables selected by nC; returns false on an invalid code.
- * chroma_dc: 0 no, 1 4:2:0 (nC = -1), 2 4:2:2 (nC = -2). */
-__device__ __forceinline__ bool vlc_coeff_token(const VlcLanes &t, WaveBits &s,
-						uint32_t lane, uint32_t nC,
-						uint32_t chroma_dc, uint32_t &t1,
-						uint32_t &tc)
+/* coeff_token for the tables selected by nC.  chroma_dc: 0 no, 1 4:2:0
+ * (nC = -1), 2 4:2:2 (nC = -2).  Returns the bad flag. */
+__device__ __forceinline__ uint32_t vlc_coeff_token(const VlcLanes &t, WaveBits &s,
+						    uint32_t lane, uint32_t nC,
+						    uint32_t chroma_dc, uint32_t &t1,
+						    uint32_t &tc)
 {
 	uint32_t bits = wb_peek(s, lane);
-	int hit;
-	uint32_t len, val;
-	if (chroma_dc) {
-		wb_mask_t g = chroma_dc == 1 ? vlc_group(0, 14) : vlc_group(16, 30);
-		hit = vlc_find(t.r[9], t.r[10], bits, g);
-		if (hit < 0)
-			return false;
-		len = vlc_len(t.r[9], hit);
-		val = (uint32_t)__builtin_amdgcn_readlane((int)t.r[11], hit);
-	} else if (nC >= 8) {
+	if (chroma_dc == 0 && nC >= 8) {
 		/* 6-bit fixed length code: xxxxyy, TotalCoeff = xxxx + 1,
 		 * TrailingOnes = yy; 0000 11 means no coefficient */
 		uint32_t c = bits >> 26;
+		uint32_t none = c == 3 ? 1u : 0u;
 		wb_skip(s, 6);
-		if (c == 3) {
-			t1 = 0;
-			tc = 0;
-			return true;
-		}
-		t1 = c & 3u;
-		tc = (c >> 2) + 1u;
-		return t1 <= tc; /* 0000 10 and 0001 11 are not code words */
-	} else {
-		const wb_mask_t g = vlc_group(0, 62);
-		if (nC < 2) {
-			hit = vlc_find(t.r[0], t.r[1], bits, g);
-			if (hit < 0)
-				return false;
-			len = vlc_len(t.r[0], hit);
-			val = (uint32_t)__builtin_amdgcn_readlane((int)t.r[2], hit);
-		} else if (nC < 4) {
-			hit = vlc_find(t.r[3], t.r[4], bits, g);
-			if (hit < 0)
-				return false;
-			len = vlc_len(t.r[3], hit);
-			val = (uint32_t)__builtin_amdgcn_readlane((int)t.r[5], hit);
-		} else {
-			hit = vlc_find(t.r[6], t.r[7], bits, g);
-			if (hit < 0)
-				return false;
-			len = vlc_len(t.r[6], hit);
-			val = (uint32_t)__builtin_amdgcn_readlane((int)t.r[8], hit);
-		}
+		t1 = none ? 0u : c & 3u;
+		tc = none ? 0u : (c >> 2) + 1u;
+		/* 0000 10 and 0001 11 are not code words */
+		uint32_t bad = t1 > tc ? 1u : 0u;
+		tc = bad ? 0u : tc;
+		return bad;
 	}
-	wb_skip(s, len);
-	t1 = (val >> 5) & 3u;
-	tc = val & 31u;
-	return true;
+	uint32_t mrow, crow, vrow;
+	wb_mask_t g;
+	if (chroma_dc) {
+		mrow = t.r[9];
+		crow = t.r[10];
+		vrow = t.r[11];
+		g = chroma_dc == 1 ? vlc_group(0, 14) : vlc_group(16, 30);
+	} else {
+		mrow = nC < 2 ? t.r[0] : nC < 4 ? t.r[3] : t.r[6];
+		crow = nC < 2 ? t.r[1] : nC < 4 ? t.r[4] : t.r[7];
+		vrow = nC < 2 ? t.r[2] : nC < 4 ? t.r[5] : t.r[8];
+		g = vlc_group(0, 62);
+	}
+	int hit = vlc_find(mrow, crow, bits, g);
+	uint32_t bad = (uint32_t)hit >> 31;
+	uint32_t len = vlc_len(mrow, hit & 63);
+	uint32_t val = (uint32_t)__builtin_amdgcn_readlane((int)vrow, hit & 63);
+	wb_skip(s, bad ? 0u : len);
+	t1 = bad ? 0u : (val >> 5) & 3u;
+	tc = bad ? 0u : val & 31u;
+	return bad;
 }
 
 /* total_zeros; maxnum selects the table family (4: chroma DC 2x2, 8: chroma
  * DC 2x4, otherwise 4x4 with tzVlcIndex = tc).  Caller guarantees
- * 1 <= tc < maxnum. */
-__device__ __forceinline__ bool vlc_total_zeros(const VlcLanes &t, WaveBits &s,
-						uint32_t lane, uint32_t tc,
-						uint32_t maxnum, uint32_t &tz)
+ * 1 <= tc < maxnum.  Returns the bad flag. */
+__device__ __forceinline__ uint32_t vlc_total_zeros(const VlcLanes &t, WaveBits &s,
+						    uint32_t lane, uint32_t tc,
+						    uint32_t maxnum, uint32_t &tz)
 {
 	uint32_t bits = wb_peek(s, lane);
-	uint32_t base, n, len;
-	int hit;
+	uint32_t base, n, bad = 0, mrow, crow;
 	if (maxnum == 4) {
-		if (tc > 3)
-			return false;
+		bad = tc > 3 ? 1u : 0u;
 		base = 5u * (tc - 1u) - tc * (tc - 1u) / 2u;
 		n = 5u - tc;
-		hit = vlc_find(t.r[18], t.r[19], bits, vlc_group(base, n));
-		if (hit < 0)
-			return false;
-		len = vlc_len(t.r[18], hit);
+		mrow = t.r[18];
+		crow = t.r[19];
 	} else if (maxnum == 8) {
-		if (tc > 7)
-			return false;
+		bad = tc > 7 ? 1u : 0u;
 		base = 16u + 9u * (tc - 1u) - tc * (tc - 1u) / 2u;
 		n = 9u - tc;
-		hit = vlc_find(t.r[18], t.r[19], bits, vlc_group(base, n));
-		if (hit < 0)
-			return false;
-		len = vlc_len(t.r[18], hit);
+		mrow = t.r[18];
+		crow = t.r[19];
 	} else {
 		/* cum(t) = lanes used by tables 1..t-1 */
 		uint32_t cum = 17u * (tc - 1u) - tc * (tc - 1u) / 2u;
-		if (tc > 15)
-			return false;
+		bad = tc > 15 ? 1u : 0u;
 		n = 17u - tc;
-		if (tc <= 4) {
-			base = cum;
-			hit = vlc_find(t.r[12], t.r[13], bits, vlc_group(base, n));
-			if (hit < 0)
-				return false;
-			len = vlc_len(t.r[12], hit);
-		} else if (tc <= 9) {
-			base = cum - 58u;
-			hit = vlc_find(t.r[14], t.r[15], bits, vlc_group(base, n));
-			if (hit < 0)
-				return false;
-			len = vlc_len(t.r[14], hit);
-		} else {
-			base = cum - 108u;
-			hit = vlc_find(t.r[16], t.r[17], bits, vlc_group(base, n));
-			if (hit < 0)
-				return false;
-			len = vlc_len(t.r[16], hit);
-		}
+		base = tc <= 4 ? cum : tc <= 9 ? cum - 58u : cum - 108u;
+		mrow = tc <= 4 ? t.r[12] : tc <= 9 ? t.r[14] : t.r[16];
+		crow = tc <= 4 ? t.r[13] : tc <= 9 ? t.r[15] : t.r[17];
 	}
-	wb_skip(s, len);
-	tz = (uint32_t)hit - base;
-	return true;
+	base = bad ? 0u : base;
+	n = bad ? 1u : n;
+	int hit = vlc_find(mrow, crow, bits, vlc_group(base, n));
+	bad |= (uint32_t)hit >> 31;
+	uint32_t len = vlc_len(mrow, hit & 63);
+	wb_skip(s, bad ? 0u : len);
+	tz = bad ? 0u : (uint32_t)hit - base;
+	return bad;
 }
 
-/* run_before with zeros_left >= 1 */
-__device__ __forceinline__ bool vlc_run_before(const VlcLanes &t, WaveBits &s,
-					       uint32_t lane, uint32_t zeros_left,
-					       uint32_t &run)
+/* run_before with zeros_left >= 1.  Table 9-10 in closed form: for
+ * zerosLeft <= 6 the code words have at most 3 bits and sit in a 3-bit indexed
+ * table of (len << 4 | run) bytes packed into one 64-bit constant per class;
+ * for zerosLeft > 6 the code is 3 bits (111 .. 001 -> 0 .. 6) or a unary tail
+ * (0001 -> 7, 00001 -> 8, ...). */
+__device__ __forceinline__ uint32_t vlc_run_before(const VlcLanes &t, WaveBits &s,
+						   uint32_t lane,
+						   uint32_t zeros_left,
+						   uint32_t &run)
 {
 	uint32_t bits = wb_peek(s, lane);
-	uint32_t z = zeros_left < 7u ? zeros_left : 7u;
-	uint32_t base = (z - 1u) * (z + 2u) / 2u;
-	uint32_t n = z < 7u ? z + 1u : 15u;
-	int hit = vlc_find(t.r[20], t.r[21], bits, vlc_group(base, n));
-	if (hit < 0)
-		return false;
-	wb_skip(s, vlc_len(t.r[20], hit));
-	run = (uint32_t)hit - base;
-	return true;
+	uint32_t top3 = bits >> 29;
+	if (zeros_left > 6) {
+		uint32_t lz = (uint32_t)__builtin_clz(bits | 0x00100000u);
+		uint32_t bad = (bits >> 21) == 0 ? 1u : 0u; /* > 11 bits */
+		run = top3 ? 7u - top3 : lz + 4u;
+		wb_skip(s, bad ? 0u : (top3 ? 3u : lz + 1u));
+		run = bad ? 0u : run;
+		return bad;
+	}
+	/* lane z of rows 20/21 holds the table of class z (vlc_load) */
+	uint64_t tb = ((uint64_t)(uint32_t)__builtin_amdgcn_readlane(
+			       (int)t.r[21], (int)zeros_left)
+		       << 32) |
+		      (uint32_t)__builtin_amdgcn_readlane((int)t.r[20],
+							  (int)zeros_left);
+	uint32_t e = (uint32_t)(tb >> (8u * top3)) & 0xffu;
+	wb_skip(s, e >> 4);
+	run = e & 15u;
+	return 0;
 }
 
 #endif /* H264_AMD_VLC_LANES_HIP_H */

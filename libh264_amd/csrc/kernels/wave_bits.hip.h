@@ -380,7 +380,12 @@ __device__ __forceinline__ uint32_t wb_peek(WaveBits &s, uint32_t lane)
 	uint32_t hi = (uint32_t)__builtin_amdgcn_readlane((int)s.wreg, (int)d);
 	uint32_t lo = (uint32_t)__builtin_amdgcn_readlane((int)s.wreg, (int)d + 1);
 	uint64_t v = ((uint64_t)hi << 32) | lo;
-	return (uint32_t)((v << sh) >> 32);
+	uint32_t r = (uint32_t)((v << sh) >> 32);
+	/* opaque to the optimiser: comparisons of the result must stay 32-bit
+	 * scalar compares instead of being folded into 64-bit compares of the
+	 * unshifted pair, which only the vector ALU has */
+	asm volatile("" : "+s"(r));
+	return r;
 }
 
 __device__ __forceinline__ void wb_skip(WaveBits &s, uint32_t n)
