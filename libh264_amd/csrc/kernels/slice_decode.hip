@@ -458,8 +458,8 @@ struct MbCtx {
 	int top_slot; /* row-context byte holding an external B neighbour or -1 */
 	int row_slot; /* row-context byte this lane saves (bottom row) or -1 */
 	uint32_t info_n, info_i16; /* lane = residual step: block parameters */
+	uint32_t bothv; /* per lane: 1 when both neighbours are available */
 	/* uniform */
-	uint64_t both; /* lanes with both neighbours available */
 	uint32_t availA, availB;
 };
 
@@ -555,16 +555,19 @@ __device__ __forceinline__ void sd_mb_begin(MbCtx &m, const uint8_t *row,
 	m.sum = (extA ? lv : 0u) + (extB ? tv : 0u);
 	bool hasA = m.a_int != 0xffu || extA;
 	bool hasB = m.b_int != 0xffu || extB;
-	m.both = __ballot(hasA && hasB);
+	m.bothv = (hasA && hasB) ? 1u : 0u;
 }
 
-/* nC of the block at lane l (9.2.1): (nA + nB + 1) >> 1 with both neighbours,
- * the available one alone otherwise, 0 with none */
+/* nC of every block (9.2.1), per lane: (nA + nB + 1) >> 1 with both
+ * neighbours, the available one alone otherwise, 0 with none */
+__device__ __forceinline__ uint32_t sd_nc_all(const MbCtx &m)
+{
+	return (m.sum + m.bothv) >> m.bothv;
+}
+
 __device__ __forceinline__ uint32_t sd_nc(const MbCtx &m, uint32_t l)
 {
-	uint32_t s = (uint32_t)__builtin_amdgcn_readlane((int)m.sum, (int)l);
-	uint32_t bb = (uint32_t)(m.both >> l) & 1u;
-	return (s + bb) >> bb;
+	return (uint32_t)__builtin_amdgcn_readlane((int)sd_nc_all(m), (int)l);
 }
 
 /* block at lane l now has TotalCoeff tc (it may have had another value: the
@@ -762,24 +765,28 @@ __device__ __forceinline__ void sd_next_mb(MbCtx &m, uint8_t *row, uint8_t *dump
 }
 
 /* ---- slice data (ref src/h264_syntax_slice_data.h:701-787) -------------- */
+/* ONLY_I: instantiated for I slices (not SI) alone, so that everything the
+ * P / B / SI syntax needs is compiled out of the intra loop instead of being
+ * carried through it in registers. */
+template <bool ONLY_I>
 __device__ __forceinline__ int
 sd_slice_data(WaveBits &wb, const VlcLanes &vt, uint32_t cbp_map, uint32_t lane,
 	      uint8_t *stage, uint8_t *row, const SliceState &S, OutCtx &o,
 	      uint32_t mb_capacity, uint32_t &mb_count)
 {
 	const uint32_t cat = S.cat, W = S.W;
-	const bool is_i = S.slice_type == H264_SLICE_TYPE_I ||
-			  S.slice_type == H264_SLICE_TYPE_SI;
-	const bool is_b = S.slice_type == H264_SLICE_TYPE_B;
-	const bool is_p = S.slice_type == H264_SLICE_TYPE_P ||
-			  S.slice_type == H264_SLICE_TYPE_SP;
+	const bool is_si = !ONLY_I && S.slice_type == H264_SLICE_TYPE_SI;
+	const bool is_i = ONLY_I || S.slice_type == H264_SLICE_TYPE_I || is_si;
+	const bool is_b = !ONLY_I && S.slice_type == H264_SLICE_TYPE_B;
+	const bool is_p = !ONLY_I && (S.slice_type == H264_SLICE_TYPE_P ||
+				      S.slice_type == H264_SLICE_TYPE_SP);
 	const bool chroma12 = cat == 1 || cat == 2;
 	const uint32_t nchroma = cat == 1 ? 4u : 8u; /* 4x4 blocks per component */
 	bool ok = true;
 	MbCtx m;
 	m.cur = m.left = m.sum = 0;
 	m.availA = m.availB = 0;
-	m.both = 0;
+	m.bothv = 0;
 	sd_mb_consts(m, lane, cat);
 	uint32_t mbx = S.first_mb % W;
 	uint32_t mbidx = 0;
@@ -828,7 +835,7 @@ sd_slice_data(WaveBits &wb, const VlcLanes &vt, uint32_t cbp_map, uint32_t lane,
 		bool intra = is_i; /* decode t with the I-slice table */
 		RD_UE(raw_type);
 		t = raw_type;
-		if (S.slice_type == H264_SLICE_TYPE_SI) {
+		if (is_si) {
 			if (t == 0) {
 				mb_type = H264_MB_TYPE_SI;
 				nparts = 1;
@@ -1099,13 +1106,45 @@ sd_slice_data(WaveBits &wb, const VlcLanes &vt, uint32_t cbp_map, uint32_t lane,
 				const uint32_t vinfo = i16 ? m.info_i16 : m.info_n;
 				uint32_t err = 0;
 				while (todo) {
+					wb_sync(wb, lane);
+					/* Runs of empty blocks.  With nC < 2 the code
+					 * word for "no coefficient" is a single 1 bit
+					 * (Table 9-5), and an empty block changes no
+					 * neighbour sum, so nC of the blocks behind it
+					 * is already known: the run is the string of 1
+					 * bits at the cursor, as far as the next coded
+					 * blocks all have nC < 2 (and a clean nz slot,
+					 * which rules out a parked DC count). */
+					uint32_t peek = wb_peek(wb, lane);
+					if ((int32_t)peek < 0) {
+						uint32_t e = (sd_nc_all(m) < 2u && m.cur == 0u)
+								     ? 1u : 0u;
+						uint32_t es = (uint32_t)__shfl((int)e,
+									       (int)(vinfo & 63u));
+						uint64_t ok_steps = __ballot(
+							es != 0 && ((vinfo >> 11) & 3u) == 0);
+						uint64_t blockers = todo & ~ok_steps;
+						uint64_t below = blockers
+							? (blockers & (0ull - blockers)) - 1ull
+							: ~0ull;
+						uint32_t k = (uint32_t)__builtin_popcountll(
+							todo & below);
+						uint32_t ones = (uint32_t)__builtin_clz(
+							~peek | 1u);
+						uint32_t run = k < ones ? k : ones;
+						if (run) {
+							wb_skip(wb, run);
+							for (uint32_t r = 0; r < run; r++)
+								todo &= todo - 1ull;
+							continue;
+						}
+					}
 					uint32_t step = (uint32_t)__builtin_ctzll(todo);
 					todo &= todo - 1ull;
 					uint32_t info = (uint32_t)__builtin_amdgcn_readlane(
 						(int)vinfo, (int)step);
 					uint32_t nzlane = info & 63u;
 					uint32_t tc;
-					wb_sync(wb, lane);
 					err |= sd_residual_block(
 						wb, vt, lane, stage, sd_nc(m, nzlane),
 						(info >> 11) & 3u, (info >> 6) & 31u,
@@ -1269,9 +1308,14 @@ h264_amd_k_decode_slices(sd_args a)
 				VlcLanes vt;
 				vlc_load(vt, a.vlc, lane);
 				uint32_t cbp_map = a.vlc->e[VLC_ROWS][lane];
-				status = sd_slice_data(wb, vt, cbp_map, lane, stage,
-						       row, S, o, a.mb_capacity,
-						       mb_count);
+				if (S.slice_type == H264_SLICE_TYPE_I)
+					status = sd_slice_data<true>(
+						wb, vt, cbp_map, lane, stage, row, S, o,
+						a.mb_capacity, mb_count);
+				else
+					status = sd_slice_data<false>(
+						wb, vt, cbp_map, lane, stage, row, S, o,
+						a.mb_capacity, mb_count);
 				end_bit = wb_pos(wb);
 			}
 		}

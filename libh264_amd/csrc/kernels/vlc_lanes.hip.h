@@ -58,6 +58,15 @@ __device__ __forceinline__ void vlc_load(VlcLanes &t, const dev_vlc_tables *src,
 	t.r[21] = (uint32_t)(tb >> 32);
 }
 
+/* A table row as an opaque vector value: without this the optimiser merges
+ * "cond ? r[i] : r[j]" into r[cond ? i : j], a dynamic index that forces the
+ * whole row array out of registers into scratch memory. */
+__device__ __forceinline__ uint32_t vlc_row(uint32_t x)
+{
+	asm("" : "+v"(x));
+	return x;
+}
+
 /* Decoders below never branch on a malformed code word: they return a "bad"
  * flag (0 / 1) for the caller to OR into its error word and hand back benign
  * values, so that the parse loop carries plain 32-bit integers instead of
@@ -107,14 +116,14 @@ __device__ __forceinline__ uint32_t vlc_coeff_token(const VlcLanes &t, WaveBits 
 	uint32_t mrow, crow, vrow;
 	wb_mask_t g;
 	if (chroma_dc) {
-		mrow = t.r[9];
-		crow = t.r[10];
-		vrow = t.r[11];
+		mrow = vlc_row(t.r[9]);
+		crow = vlc_row(t.r[10]);
+		vrow = vlc_row(t.r[11]);
 		g = chroma_dc == 1 ? vlc_group(0, 14) : vlc_group(16, 30);
 	} else {
-		mrow = nC < 2 ? t.r[0] : nC < 4 ? t.r[3] : t.r[6];
-		crow = nC < 2 ? t.r[1] : nC < 4 ? t.r[4] : t.r[7];
-		vrow = nC < 2 ? t.r[2] : nC < 4 ? t.r[5] : t.r[8];
+		mrow = nC < 2 ? vlc_row(t.r[0]) : nC < 4 ? vlc_row(t.r[3]) : vlc_row(t.r[6]);
+		crow = nC < 2 ? vlc_row(t.r[1]) : nC < 4 ? vlc_row(t.r[4]) : vlc_row(t.r[7]);
+		vrow = nC < 2 ? vlc_row(t.r[2]) : nC < 4 ? vlc_row(t.r[5]) : vlc_row(t.r[8]);
 		g = vlc_group(0, 62);
 	}
 	int hit = vlc_find(mrow, crow, bits, g);
@@ -140,22 +149,22 @@ __device__ __forceinline__ uint32_t vlc_total_zeros(const VlcLanes &t, WaveBits 
 		bad = tc > 3 ? 1u : 0u;
 		base = 5u * (tc - 1u) - tc * (tc - 1u) / 2u;
 		n = 5u - tc;
-		mrow = t.r[18];
-		crow = t.r[19];
+		mrow = vlc_row(t.r[18]);
+		crow = vlc_row(t.r[19]);
 	} else if (maxnum == 8) {
 		bad = tc > 7 ? 1u : 0u;
 		base = 16u + 9u * (tc - 1u) - tc * (tc - 1u) / 2u;
 		n = 9u - tc;
-		mrow = t.r[18];
-		crow = t.r[19];
+		mrow = vlc_row(t.r[18]);
+		crow = vlc_row(t.r[19]);
 	} else {
 		/* cum(t) = lanes used by tables 1..t-1 */
 		uint32_t cum = 17u * (tc - 1u) - tc * (tc - 1u) / 2u;
 		bad = tc > 15 ? 1u : 0u;
 		n = 17u - tc;
 		base = tc <= 4 ? cum : tc <= 9 ? cum - 58u : cum - 108u;
-		mrow = tc <= 4 ? t.r[12] : tc <= 9 ? t.r[14] : t.r[16];
-		crow = tc <= 4 ? t.r[13] : tc <= 9 ? t.r[15] : t.r[17];
+		mrow = tc <= 4 ? vlc_row(t.r[12]) : tc <= 9 ? vlc_row(t.r[14]) : vlc_row(t.r[16]);
+		crow = tc <= 4 ? vlc_row(t.r[13]) : tc <= 9 ? vlc_row(t.r[15]) : vlc_row(t.r[17]);
 	}
 	base = bad ? 0u : base;
 	n = bad ? 1u : n;
