@@ -120,61 +120,57 @@ static code_word parse_bits(const char *s)
 	return c;
 }
 
-static void put_word(dev_vlc_tables *t, int row, uint32_t lane, const char *bits)
+static void put_entry(dev_vlc_entry *e, const char *bits, uint32_t payload)
 {
 	code_word c = parse_bits(bits);
-	t->e[row][lane] = c.mask;
-	t->e[row + 1][lane] = c.code;
+	e->mask = c.mask;
+	e->cw = c.code | payload | c.len; /* len in bits 0-4 of every payload */
 }
 
 /* Layout documented in kernels/vlc_lanes.hip.h */
 static void vlc_build_tables(dev_vlc_tables *t)
 {
-	uint32_t next[6] = {0, 0, 0, 0, 0, 16};
-	for (int r = 0; r < DEV_VLC_TABLES; r++)
-		for (int l = 0; l < 64; l++)
-			t->e[r][l] = 0;
-	/* unused lanes: mask 0 / code 1 never matches */
-	for (int r = 0; r < 22; r++) {
-		bool is_code_row = r < 12 ? (r % 3) == 1 : ((r - 12) % 2) == 1;
-		if (is_code_row)
-			for (int l = 0; l < 64; l++)
-				t->e[r][l] = 1;
-	}
+	uint32_t next[DEV_VLC_CT_CLASSES] = {0, 0, 0, 0, 0, 0};
+	uint32_t tz_n[DEV_VLC_TZ_TABLES];
+	memset(t, 0, sizeof(*t));
+	memset(tz_n, 0, sizeof(tz_n));
+	/* the .inc numbers the columns 0,1,2 (nC ranges), 3 (6-bit FLC, nC >= 8),
+	 * 4 and 5 (chroma DC): the same order as the classes here */
 #define H264_CT(col, bits, t1, tc)                                             \
-	do {                                                                   \
-		if ((col) != 3) {                                              \
-			int row = (col) <= 2 ? 3 * (col) : 9;                  \
-			uint32_t lane = next[col]++;                           \
-			put_word(t, row, lane, bits);                          \
-			t->e[row + 2][lane] = ((t1) << 5) | (tc);              \
-		}                                                              \
-	} while (0);
+	put_entry(&t->ct[col][next[col]++], bits,                              \
+		  ((uint32_t)(t1) << 5) | ((uint32_t)(tc) << 7));
 #define H264_TZ(idx, bits, v)                                                  \
 	do {                                                                   \
-		uint32_t cum = 17u * ((idx)-1u) - (idx) * ((idx)-1u) / 2u;     \
-		int row = (idx) <= 4 ? 12 : (idx) <= 9 ? 14 : 16;              \
-		uint32_t base = (idx) <= 4 ? cum                               \
-				: (idx) <= 9 ? cum - 58u                       \
-					     : cum - 108u;                     \
-		put_word(t, row, base + (v), bits);                            \
+		put_entry(&t->tz[(idx)-1][v], bits, 0);                        \
+		tz_n[(idx)-1]++;                                               \
 	} while (0);
 #define H264_TZ_C420(idx, bits, v)                                             \
-	put_word(t, 18, 5u * ((idx)-1u) - (idx) * ((idx)-1u) / 2u + (v), bits);
+	do {                                                                   \
+		put_entry(&t->tz[14 + (idx)][v], bits, 0);                     \
+		tz_n[14 + (idx)]++;                                            \
+	} while (0);
 #define H264_TZ_C422(idx, bits, v)                                             \
-	put_word(t, 18, 16u + 9u * ((idx)-1u) - (idx) * ((idx)-1u) / 2u + (v), bits);
-#define H264_RB(idx, bits, v)                                                  \
-	put_word(t, 20, ((idx)-1u) * ((idx) + 2u) / 2u + (v), bits);
+	do {                                                                   \
+		put_entry(&t->tz[17 + (idx)][v], bits, 0);                     \
+		tz_n[17 + (idx)]++;                                            \
+	} while (0);
 #define H264_CBP(cls, code, intra, inter)                                      \
-	t->e[22][code] |= ((uint32_t)(intra) << (16 * (cls))) |                \
-			  ((uint32_t)(inter) << (16 * (cls) + 8));
+	t->cbp[code] |= ((uint32_t)(intra) << (16 * (cls))) |                  \
+			((uint32_t)(inter) << (16 * (cls) + 8));
 #include "common/h264_cavlc_tables.inc"
 #undef H264_CT
 #undef H264_TZ
 #undef H264_TZ_C420
 #undef H264_TZ_C422
-#undef H264_RB
 #undef H264_CBP
+	/* entries without a code word repeat entry 0 of their table: the decoder
+	 * takes the lowest matching entry, so a duplicate never wins */
+	for (int c = 0; c < DEV_VLC_CT_CLASSES; c++)
+		for (uint32_t l = next[c]; l < 64; l++)
+			t->ct[c][l] = t->ct[c][0];
+	for (int k = 0; k < DEV_VLC_TZ_TABLES; k++)
+		for (uint32_t l = tz_n[k]; l < 16; l++)
+			t->tz[k][l] = t->tz[k][0];
 }
 
 /* ---- engine ----------------------------------------------------------------- */
@@ -554,7 +550,8 @@ extern "C" int h264_amd_decode_slices(struct h264_amd_engine *e,
 	a.mb_out = args->d_mb_out;
 	a.row_pitch = params->max_width_mbs;
 
-	size_t lds = SD_ROW_OFF + 16u * (size_t)a.row_pitch;
+	a.wave_lds_bytes = (SD_ROW_OFF + 16u * a.row_pitch + 255u) & ~255u;
+	size_t lds = SD_TABS_BYTES + (size_t)SD_WAVES_PER_BLOCK * a.wave_lds_bytes;
 	if (lds > 160u * 1024u)
 		return -E2BIG;
 	if (lds > 48u * 1024u)
@@ -562,8 +559,9 @@ extern "C" int h264_amd_decode_slices(struct h264_amd_engine *e,
 			(const void *)h264_amd_k_decode_slices,
 			hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
 	HIP_TRY(hipEventRecord(e->ev[FAM_DECODE][0], e->stream));
-	hipLaunchKernelGGL(h264_amd_k_decode_slices, dim3(a.n), dim3(64), lds,
-			   e->stream, a);
+	hipLaunchKernelGGL(h264_amd_k_decode_slices,
+			   dim3((a.n + SD_WAVES_PER_BLOCK - 1) / SD_WAVES_PER_BLOCK),
+			   dim3(64 * SD_WAVES_PER_BLOCK), lds, e->stream, a);
 	HIP_TRY(hipGetLastError());
 	HIP_TRY(hipEventRecord(e->ev[FAM_DECODE][1], e->stream));
 	e->timed[FAM_DECODE] = true;

@@ -62,11 +62,22 @@ struct dev_epoch {
 	uint16_t sps_ver[32];
 };
 
-/* lane-resident prefix-code tables: [row][lane], rows 0..21 described in
- * vlc_lanes.hip.h, row 22 = coded_block_pattern mapping (lane = codeNum) */
-#define DEV_VLC_TABLES 23
-struct dev_vlc_tables {
-	uint32_t e[DEV_VLC_TABLES][64];
+/* CAVLC prefix-code tables as the slice kernel keeps them in LDS (layout and
+ * use: vlc_lanes.hip.h).  One code word per entry: mask covers the code's bits
+ * (left aligned), cw = the code left aligned | payload in the low 16 bits. */
+struct dev_vlc_entry {
+	uint32_t mask, cw;
 };
+#define DEV_VLC_CT_CLASSES 6 /* nC<2, <4, <8, >=8 (FLC), chroma DC 420, 422 */
+#define DEV_VLC_TZ_TABLES 25 /* 4x4 tzVlcIndex 1..15, 2x2 1..3, 2x4 1..7 */
+struct dev_vlc_tables {
+	struct dev_vlc_entry ct[DEV_VLC_CT_CLASSES][64];
+	struct dev_vlc_entry tz[DEV_VLC_TZ_TABLES][16];
+	/* coded_block_pattern mapping, entry = codeNum: bytes cat 1/2 intra,
+	 * inter, cat 0/3 intra, inter (Table 9-4) */
+	uint32_t cbp[64];
+};
+#define DEV_VLC_LDS_BYTES                                                      \
+	((DEV_VLC_CT_CLASSES * 64 + DEV_VLC_TZ_TABLES * 16) * 8)
 
 #endif /* H264_AMD_DEV_PARAMS_H */

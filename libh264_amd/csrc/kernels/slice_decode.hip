@@ -38,6 +38,11 @@
 #include "vlc_lanes.hip.h"
 #include "wave_bits.hip.h"
 
+/* LDS: the workgroup's copy of the CAVLC tables, then one private block per
+ * wave (SD_WAVES_PER_BLOCK slices per workgroup share the tables) */
+#define SD_WAVES_PER_BLOCK 4u
+#define SD_TABS_BYTES ((DEV_VLC_LDS_BYTES + 255u) & ~255u)
+/* offsets inside a wave's block */
 #define SD_RING_OFF 0u
 #define SD_STATE_OFF 1024u
 #define SD_DUMP_OFF (1024u + WB_STATE_BYTES)
@@ -583,12 +588,63 @@ __device__ __forceinline__ void sd_nz_set(MbCtx &m, uint32_t l, uint32_t tc,
 	}
 }
 
+/* The n (16 or 4) prev_intra_pred_mode_flag / rem_intra_pred_mode pairs of an
+ * I_NxN macroblock (ref src/h264_syntax_slice_data.h:520-553), all at once.
+ * Every symbol is '1' or '0xxx', so lane k speculates on a symbol starting at
+ * bit k of the next 64 bits: next[k] = k + (1 or 4).  Pointer doubling turns
+ * that into next^2, next^4 ... and lane j composes them along the bits of j to
+ * land on the start of symbol j.  Seven cross-lane gathers instead of up to 32
+ * dependent scalar reads.  Stores the packed nibbles (mode + 1, 0 = predicted)
+ * into bytes 8..15 of the staged record and returns the bits consumed. */
+__device__ __forceinline__ uint32_t sd_gather(uint32_t table, uint32_t idx)
+{
+	uint32_t v = (uint32_t)__shfl((int)table, (int)(idx & 63u));
+	return idx >= 64u ? idx : v;
+}
+
+__device__ __forceinline__ uint32_t sd_intra_pred_modes(WaveBits &wb, uint32_t lane,
+							uint32_t n, uint8_t *stage)
+{
+	uint32_t hi = wb_peek(wb, lane);
+	wb.bitpos += 32u;
+	uint32_t lo = wb_peek(wb, lane);
+	wb.bitpos -= 32u;
+	const uint64_t win = ((uint64_t)hi << 32) | lo;
+	uint32_t flag = (uint32_t)(win >> (63u - lane)) & 1u;
+	uint32_t j1 = lane + (flag ? 1u : 4u);
+	uint32_t j2 = sd_gather(j1, j1);
+	uint32_t j4 = sd_gather(j2, j2);
+	uint32_t j8 = sd_gather(j4, j4);
+	uint32_t j16 = sd_gather(j8, j8);
+	/* every gather runs in all lanes (a cross-lane read must not sit in a
+	 * divergent branch); the lane then keeps or drops the result */
+	uint32_t p = 0, g;
+	g = sd_gather(j1, p);
+	p = (lane & 1u) ? g : p;
+	g = sd_gather(j2, p);
+	p = (lane & 2u) ? g : p;
+	g = sd_gather(j4, p);
+	p = (lane & 4u) ? g : p;
+	g = sd_gather(j8, p);
+	p = (lane & 8u) ? g : p;
+	g = sd_gather(j16, p);
+	p = (lane & 16u) ? g : p;
+	/* lane j < n: symbol j starts at bit p (< 64) */
+	uint32_t sym = (uint32_t)((win << (p & 63u)) >> 60);
+	uint32_t nib = (sym & 8u) ? 0u : (sym & 7u) + 1u;
+	uint32_t nxt = (uint32_t)__shfl_down((int)nib, 1);
+	bool mine = lane < n && (lane & 1u) == 0;
+	*lds_sel(stage + 8u + (lane >> 1), stage - SD_DUMP_BYTES, mine, lane) =
+		(uint8_t)(nib | (nxt << 4));
+	return (uint32_t)__builtin_amdgcn_readlane((int)p, (int)n);
+}
+
 /* 9.2 residual_block (ref src/h264_syntax_slice_data.h:103-242).  The decoded
  * levels go to stage[coef_off ...] (int16 units from the record start).
  * Returns an error flag (non-zero: the slice ends with -EIO); tc_out =
  * TotalCoeff.  Malformed codes do not branch out: they raise the flag and the
  * walk goes on with benign values until the caller looks at it. */
-__device__ __forceinline__ uint32_t sd_residual_block(WaveBits &wb, const VlcLanes &vt,
+__device__ __forceinline__ uint32_t sd_residual_block(WaveBits &wb, const VlcTabs &vt,
 						      uint32_t lane, uint8_t *stage,
 						      uint32_t nC, uint32_t chroma_dc,
 						      uint32_t maxnum, uint32_t coef_off,
@@ -770,7 +826,7 @@ __device__ __forceinline__ void sd_next_mb(MbCtx &m, uint8_t *row, uint8_t *dump
  * carried through it in registers. */
 template <bool ONLY_I>
 __device__ __forceinline__ int
-sd_slice_data(WaveBits &wb, const VlcLanes &vt, uint32_t cbp_map, uint32_t lane,
+sd_slice_data(WaveBits &wb, const VlcTabs &vt, uint32_t cbp_map, uint32_t lane,
 	      uint8_t *stage, uint8_t *row, const SliceState &S, OutCtx &o,
 	      uint32_t mb_capacity, uint32_t &mb_count)
 {
@@ -1008,15 +1064,8 @@ sd_slice_data(WaveBits &wb, const VlcLanes &vt, uint32_t cbp_map, uint32_t lane,
 				if (pm0 == PM_I4x4 || pm0 == PM_I8x8 || pm0 == PM_I16x16) {
 					if (pm0 != PM_I16x16) {
 						uint32_t n = pm0 == PM_I4x4 ? 16u : 4u;
-						for (uint32_t b = 0; b < n; b++) {
-							uint32_t nib = 0;
-							if (!wb_u1(wb, lane))
-								nib = wb_u(wb, lane, 3) + 1u;
-							if (b < 8)
-								pred_lo |= nib << (4u * b);
-							else
-								pred_hi |= nib << (4u * (b - 8u));
-						}
+						wb_skip(wb, sd_intra_pred_modes(wb, lane, n,
+										stage));
 					}
 					if (chroma12)
 						RD_UE(icp);
@@ -1168,8 +1217,11 @@ sd_slice_data(WaveBits &wb, const VlcLanes &vt, uint32_t cbp_map, uint32_t lane,
 					 ((icp & 0xffu) << 16) | (i16pred << 24);
 			lds_w32(stage, 0, word0, lane);
 			lds_w32(stage, 4, word1, lane);
-			lds_w32(stage, 8, pred_lo, lane);
-			lds_w32(stage, 12, pred_hi, lane);
+			/* intra prediction modes are already in place */
+			if (pred_lo | pred_hi) {
+				lds_w32(stage, 8, pred_lo, lane);
+				lds_w32(stage, 12, pred_hi, lane);
+			}
 			*lds_sel(stage + 16u + lane, stage - SD_DUMP_BYTES, lane < 48,
 				 lane) = (uint8_t)m.cur;
 		}
@@ -1197,17 +1249,23 @@ struct sd_args {
 	struct h264_slice_header *headers;
 	uint8_t *mb_out;
 	uint32_t row_pitch; /* macroblock columns of row context in LDS */
+	uint32_t wave_lds_bytes; /* LDS of one wave: SD_ROW_OFF + 16 * row_pitch */
 };
 
-extern "C" __global__ void __launch_bounds__(64, 4)
+extern "C" __global__ void __launch_bounds__(64 * SD_WAVES_PER_BLOCK, 4)
 h264_amd_k_decode_slices(sd_args a)
 {
-	extern __shared__ __attribute__((aligned(16))) uint8_t lds[];
+	extern __shared__ __attribute__((aligned(16))) uint8_t lds_all[];
+	vlc_stage_tables(lds_all, a.vlc, threadIdx.x, 64u * SD_WAVES_PER_BLOCK);
+	__syncthreads();
+	/* from here on the waves of the workgroup are independent */
+	const uint32_t wave = wb_uniform(threadIdx.x >> 6);
+	uint8_t *lds = lds_all + SD_TABS_BYTES + wave * a.wave_lds_bytes;
 	uint8_t *ring = lds + SD_RING_OFF;
 	uint8_t *stage = lds + SD_STAGE_OFF;
 	uint8_t *row = lds + SD_ROW_OFF;
 	const uint32_t lane = wb_lane();
-	const uint32_t slice = blockIdx.x;
+	const uint32_t slice = blockIdx.x * SD_WAVES_PER_BLOCK + wave;
 	if (slice >= a.n)
 		return;
 
@@ -1305,9 +1363,9 @@ h264_amd_k_decode_slices(sd_args a)
 				status = H264_AMD_E_UNSUPPORTED;
 			} else {
 				rflags |= H264_AMD_SR_DATA_PARSED;
-				VlcLanes vt;
-				vlc_load(vt, a.vlc, lane);
-				uint32_t cbp_map = a.vlc->e[VLC_ROWS][lane];
+				VlcTabs vt;
+				vlc_open(vt, lds_all, lane);
+				uint32_t cbp_map = a.vlc->cbp[lane];
 				if (S.slice_type == H264_SLICE_TYPE_I)
 					status = sd_slice_data<true>(
 						wb, vt, cbp_map, lane, stage, row, S, o,
