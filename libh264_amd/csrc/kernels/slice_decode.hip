@@ -666,32 +666,41 @@ __device__ __forceinline__ uint32_t sd_residual_block(WaveBits &wb, const VlcTab
 		lv = lane < t1 ? (sbit ? 0xffffu : 1u) : 0u;
 		i = t1;
 	}
+	/* levels (9.2.2.1).  first_adj: the first level after fewer than three
+	 * trailing ones cannot be +-1, so its code is offset by 2 */
+	uint32_t first_adj = t1 < 3 ? 2u : 0u;
 	for (; i < tc; i++) {
 		uint32_t bits = wb_peek(wb, lane);
-		err |= bits < (1u << 6) ? 1u : 0u; /* level_prefix > 25 */
 		uint32_t prefix = (uint32_t)__builtin_clz(bits | 0x3fu);
-		wb_skip(wb, prefix + 1u);
-		uint32_t code = (prefix < 15u ? prefix : 15u) << suffix_len;
-		uint32_t size = (prefix == 14 && suffix_len == 0) ? 4u
-				: prefix >= 15		  ? prefix - 3u
-							  : suffix_len;
-		if (size)
+		uint32_t code;
+		if (prefix < 14u + (suffix_len ? 1u : 0u)) {
+			/* the usual shape: prefix zeros, a one, suffix_len bits,
+			 * all inside the 32 bits at hand */
+			uint32_t suffix = ((bits << (prefix + 1u)) >> 1) >>
+					  (31u - suffix_len);
+			code = (prefix << suffix_len) + suffix;
+			wb_skip(wb, prefix + 1u + suffix_len);
+		} else {
+			err |= bits < (1u << 6) ? 1u : 0u; /* level_prefix > 25 */
+			wb_skip(wb, prefix + 1u);
+			code = (prefix < 15u ? prefix : 15u) << suffix_len;
+			uint32_t size = prefix == 14u ? 4u : prefix - 3u;
 			code += wb_u(wb, lane, size);
-		if (prefix >= 15 && suffix_len == 0)
-			code += 15;
-		if (prefix >= 16)
-			code += (1u << (prefix - 3u)) - 4096u;
-		if (i == t1 && t1 < 3)
-			code += 2;
-		int32_t val = (code & 1u) ? (-(int32_t)code - 1) >> 1
-					  : (int32_t)((code + 2u) >> 1);
+			if (prefix >= 15 && suffix_len == 0)
+				code += 15;
+			if (prefix >= 16)
+				code += (1u << (prefix - 3u)) - 4096u;
+		}
+		code += first_adj;
+		first_adj = 0;
+		/* even code -> +(code + 2) / 2, odd -> -(code + 1) / 2 */
+		uint32_t neg = code & 1u;
+		int32_t val = (int32_t)((((code + 2u) >> 1) ^ (0u - neg)) + neg);
 		int32_t v16 = (int16_t)val; /* levelVal is int16_t in the ref */
 		lv = wb_setlane(lv, i, (uint32_t)v16 & 0xffffu, lane);
-		if (suffix_len == 0)
-			suffix_len = 1;
-		int32_t a = v16 < 0 ? -v16 : v16;
-		if (a > (3 << (suffix_len - 1u)) && suffix_len < 6)
-			suffix_len++;
+		suffix_len = suffix_len ? suffix_len : 1u;
+		uint32_t a = (uint32_t)(v16 < 0 ? -v16 : v16);
+		suffix_len += (a > (3u << (suffix_len - 1u)) && suffix_len < 6u) ? 1u : 0u;
 	}
 	uint32_t zeros_left = 0;
 	if (tc < maxnum)
