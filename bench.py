@@ -68,17 +68,30 @@ def main():
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    # ORDER MATTERS: torch ships its own ROCm runtime (same soname as the
+    # system one the engine was linked against).  With torch initialised
+    # first the engine library resolves to that already-loaded copy and the
+    # process has ONE HIP runtime; the other way round torch finds no GPU
+    # (measured, tools/dist_probe.py).  libh264_amd loads its library lazily.
     dist = None
-    if world > 1:
+    if world > 1 or os.environ.get("H264_AMD_FORCE_DIST"):
+        # H264_AMD_FORCE_DIST: rehearse the N > 1 path on a one-GPU box
         import torch
         import torch.distributed as dist_mod
         dist = dist_mod
         torch.cuda.set_device(local_rank)
-        dist.init_process_group(backend="nccl")
+        if "MASTER_ADDR" not in os.environ:
+            os.environ["MASTER_ADDR"] = "127.0.0.1"
+            os.environ.setdefault("MASTER_PORT", "29573")
+            os.environ.setdefault("RANK", "0")
+            os.environ.setdefault("WORLD_SIZE", "1")
+        dist.init_process_group(backend="nccl",
+                                device_id=torch.device("cuda", local_rank))
     n_gpus = world
 
     import libh264_amd
     from libh264_amd import gen, Params, shard
+
     from libh264_amd.ctypes_abi import Sps, Pps, TIER_NONE, TIER_T0, TIER_T1
 
     # a GPU box gives each GPU a share of 16 host cores whatever os.cpu_count()
