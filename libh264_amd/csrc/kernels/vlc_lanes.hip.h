@@ -85,7 +85,8 @@ __device__ __forceinline__ uint32_t vlc_match(const uint8_t *row, uint32_t off,
 {
 	const uint2 e = *reinterpret_cast<const uint2 *>(row + off);
 	wb_mask_t m = __ballot(((bits ^ e.y) & e.x) == 0u);
-	hit = __builtin_ffsll((long long)m) - 1;
+	/* s_ff1 of zero is -1: "no entry matches" needs no compare */
+	asm("s_ff1_i32_b64 %0, %1" : "=s"(hit) : "s"(m));
 	bad = (uint32_t)hit >> 31;
 	return (uint32_t)__builtin_amdgcn_readlane((int)e.y, hit & 63);
 }
@@ -104,9 +105,10 @@ __device__ __forceinline__ uint32_t vlc_coeff_token(const VlcTabs &t, WaveBits &
 	uint32_t bad;
 	int hit;
 	uint32_t cw = vlc_match(t.ct + 512u * cls, t.off64, bits, bad, hit);
-	wb_skip(s, bad ? 0u : cw & 31u);
-	t1 = bad ? 0u : (cw >> 5) & 3u;
-	tc = bad ? 0u : (cw >> 7) & 31u;
+	cw &= bad - 1u; /* everything 0 on a bad code */
+	wb_skip(s, cw & 31u);
+	t1 = (cw >> 5) & 3u;
+	tc = (cw >> 7) & 31u;
 	return bad;
 }
 
@@ -125,8 +127,9 @@ __device__ __forceinline__ uint32_t vlc_total_zeros(const VlcTabs &t, WaveBits &
 	int hit;
 	uint32_t cw = vlc_match(t.tz + 128u * k, t.off16, bits, bad, hit);
 	bad |= range;
-	wb_skip(s, bad ? 0u : cw & 31u);
-	tz = bad ? 0u : (uint32_t)hit;
+	uint32_t okm = bad - 1u;
+	wb_skip(s, cw & 31u & okm);
+	tz = (uint32_t)hit & okm;
 	return bad;
 }
 
