@@ -639,6 +639,22 @@ __device__ __forceinline__ uint32_t sd_intra_pred_modes(WaveBits &wb, uint32_t l
 	return (uint32_t)__builtin_amdgcn_readlane((int)p, (int)n);
 }
 
+/* inclusive prefix sum over the 64 lanes with DPP row shifts and broadcasts
+ * (register-to-register, no LDS round trip) */
+__device__ __forceinline__ uint32_t sd_scan_add(uint32_t x)
+{
+	uint32_t v = x;
+	v += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x111, 0xf, 0xf, true);
+	v += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x112, 0xf, 0xf, true);
+	v += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x114, 0xf, 0xf, true);
+	v += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x118, 0xf, 0xf, true);
+	/* lane 15 of each row into the next row (rows 1, 3), then lane 31 into
+	 * rows 2 and 3 */
+	v += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x142, 0xa, 0xf, false);
+	v += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x143, 0xc, 0xf, false);
+	return v;
+}
+
 /* 9.2 residual_block (ref src/h264_syntax_slice_data.h:103-242).  The decoded
  * levels go to stage[coef_off ...] (int16 units from the record start).
  * Returns an error flag (non-zero: the slice ends with -EIO); tc_out =
@@ -1165,35 +1181,41 @@ sd_slice_data(WaveBits &wb, const VlcTabs &vt, uint32_t cbp_map, uint32_t lane,
 				uint32_t err = 0;
 				while (todo) {
 					wb_sync(wb, lane);
-					/* Runs of empty blocks.  With nC < 2 the code
-					 * word for "no coefficient" is a single 1 bit
-					 * (Table 9-5), and an empty block changes no
-					 * neighbour sum, so nC of the blocks behind it
-					 * is already known: the run is the string of 1
-					 * bits at the cursor, as far as the next coded
-					 * blocks all have nC < 2 (and a clean nz slot,
-					 * which rules out a parked DC count). */
+					/* Runs of empty blocks.  For nC < 8 the code word
+					 * for "no coefficient" is a string of 1, 2 or 4
+					 * one bits (Table 9-5: nC < 2, < 4, < 8), and an
+					 * empty block changes no neighbour sum, so nC of
+					 * the blocks behind it is already known.  With
+					 * the blocks still to come laid out over the
+					 * lanes in bitstream order, a prefix sum of their
+					 * code lengths against the number of leading
+					 * one bits at the cursor gives the length of the
+					 * run at once.  A block with a non-zero nz slot
+					 * (a parked DC count), nC >= 8 or a chroma DC
+					 * block ends the run. */
 					uint32_t peek = wb_peek(wb, lane);
 					if ((int32_t)peek < 0) {
-						uint32_t e = (sd_nc_all(m) < 2u && m.cur == 0u)
-								     ? 1u : 0u;
-						uint32_t es = (uint32_t)__shfl((int)e,
-									       (int)(vinfo & 63u));
-						uint64_t ok_steps = __ballot(
-							es != 0 && ((vinfo >> 11) & 3u) == 0);
-						uint64_t blockers = todo & ~ok_steps;
-						uint64_t below = blockers
-							? (blockers & (0ull - blockers)) - 1ull
-							: ~0ull;
-						uint32_t k = (uint32_t)__builtin_popcountll(
-							todo & below);
+						uint32_t ncv = sd_nc_all(m);
+						uint32_t lb = ncv < 2u ? 1u : ncv < 4u ? 2u
+							      : ncv < 8u ? 4u : 64u;
+						lb = m.cur == 0u ? lb : 64u;
+						uint32_t ls = (uint32_t)__shfl(
+							(int)lb, (int)(vinfo & 63u));
+						ls = ((vinfo >> 11) & 3u) ? 64u : ls;
+						uint32_t in_todo =
+							(uint32_t)(todo >> lane) & 1u;
+						uint32_t incl = sd_scan_add(in_todo ? ls : 0u);
 						uint32_t ones = (uint32_t)__builtin_clz(
 							~peek | 1u);
-						uint32_t run = k < ones ? k : ones;
-						if (run) {
-							wb_skip(wb, run);
-							for (uint32_t r = 0; r < run; r++)
-								todo &= todo - 1ull;
+						uint64_t fit = __ballot(in_todo != 0 &&
+									incl <= ones);
+						if (fit) {
+							uint32_t last = 63u - (uint32_t)
+								__builtin_clzll(fit);
+							wb_skip(wb, (uint32_t)
+								__builtin_amdgcn_readlane(
+									(int)incl, (int)last));
+							todo &= ~fit;
 							continue;
 						}
 					}
