@@ -456,8 +456,12 @@ __device__ __forceinline__ uint32_t wb_raw_of_clean(const WaveBits &s, uint32_t 
  * alignment and then nothing but at most ONE raw zero byte. */
 __device__ __forceinline__ bool wb_more_rbsp_data(WaveBits &s, uint32_t lane)
 {
-	uint32_t v = wb_peek(s, lane);
 	uint32_t p = wb_pos(s);
+	/* two or more RBSP bytes behind the current one: data, whatever the bits
+	 * at the cursor look like (both exits below would say so) */
+	if (s.clean_total >= (p >> 3) + 3u)
+		return true;
+	uint32_t v = wb_peek(s, lane);
 	if (wb_all_in(s) && p >= wb_total_bits(s))
 		return false;
 	uint32_t rem = 8u - (p & 7u); /* bits left in this byte */
