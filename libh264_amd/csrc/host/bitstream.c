@@ -77,6 +77,10 @@ int h264_bs_read_bits_ue(struct h264_bitstream *bs, uint32_t *v)
 			break;
 		zeros++;
 	}
+	/* 32 or more zeros: not representable (and "1 << 32" is undefined in the
+	 * reference); an error, as in the kernels */
+	if (zeros >= 32)
+		return -EIO;
 	if (zeros && h264_bs_read_bits(bs, &tail, zeros) < 0)
 		return -EIO;
 	*v = (1u << zeros) - 1u + tail;

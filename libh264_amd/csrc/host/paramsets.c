@@ -128,7 +128,9 @@ static void syn_hrd(struct h264_syn *s, struct h264_hrd *h)
 	f_u(s, &h->bit_rate_scale, 4);
 	f_u(s, &h->cpb_size_scale, 4);
 	/* same (off by one) acceptance test as the reference: 32 passes */
-	require(s, h->cpb_cnt_minus1 <= H264_ARRAY_SIZE(h->cpb));
+	/* strict bound: the reference accepts a count equal to the array size and
+	 * writes one element past it (src/h264_syntax.h:43); -EIO here */
+	require(s, h->cpb_cnt_minus1 < H264_ARRAY_SIZE(h->cpb));
 	for (i = 0; !s->err && i <= h->cpb_cnt_minus1; i++) {
 		f_ue(s, &h->cpb[i].bit_rate_value_minus1);
 		f_ue(s, &h->cpb[i].cpb_size_value_minus1);
@@ -354,7 +356,7 @@ int h264_syn_pps_body(struct h264_syn *s, const struct h264_sps *sps,
 			return s->err;
 		switch (p->slice_group_map_type) {
 		case 0:
-			require(s, p->num_slice_groups_minus1 <=
+			require(s, p->num_slice_groups_minus1 <
 					   H264_ARRAY_SIZE(p->run_length_minus1));
 			for (i = 0; !s->err && i <= p->num_slice_groups_minus1; i++)
 				f_ue(s, &p->run_length_minus1[i]);
@@ -378,7 +380,7 @@ int h264_syn_pps_body(struct h264_syn *s, const struct h264_sps *sps,
 		case 6:
 			f_ue(s, &p->pic_size_in_map_units_minus1);
 			n = h264_intlog2(p->num_slice_groups_minus1 + 1);
-			require(s, p->pic_size_in_map_units_minus1 <=
+			require(s, p->pic_size_in_map_units_minus1 <
 					   H264_ARRAY_SIZE(p->slice_group_id));
 			for (i = 0; !s->err && i <= p->pic_size_in_map_units_minus1;
 			     i++)
@@ -463,7 +465,7 @@ static void sei_buffering_period(struct h264_syn *s, struct h264_ctx *ctx,
 	if (ctx->sps->vui.nal_hrd_parameters_present_flag) {
 		hrd = &ctx->sps->vui.nal_hrd;
 		n = hrd->initial_cpb_removal_delay_length_minus1 + 1;
-		require(s, hrd->cpb_cnt_minus1 <= H264_ARRAY_SIZE(b->nal_hrd_cpb));
+		require(s, hrd->cpb_cnt_minus1 < H264_ARRAY_SIZE(b->nal_hrd_cpb));
 		for (i = 0; !s->err && i <= hrd->cpb_cnt_minus1; i++) {
 			f_u(s, &b->nal_hrd_cpb[i].initial_cpb_removal_delay, n);
 			f_u(s, &b->nal_hrd_cpb[i].initial_cpb_removal_delay_offset,
@@ -473,7 +475,7 @@ static void sei_buffering_period(struct h264_syn *s, struct h264_ctx *ctx,
 	if (ctx->sps->vui.vcl_hrd_parameters_present_flag) {
 		hrd = &ctx->sps->vui.vcl_hrd;
 		n = hrd->initial_cpb_removal_delay_length_minus1 + 1;
-		require(s, hrd->cpb_cnt_minus1 <= H264_ARRAY_SIZE(b->vcl_hrd_cpb));
+		require(s, hrd->cpb_cnt_minus1 < H264_ARRAY_SIZE(b->vcl_hrd_cpb));
 		for (i = 0; !s->err && i <= hrd->cpb_cnt_minus1; i++) {
 			f_u(s, &b->vcl_hrd_cpb[i].initial_cpb_removal_delay, n);
 			f_u(s, &b->vcl_hrd_cpb[i].initial_cpb_removal_delay_offset,
@@ -555,7 +557,7 @@ static void sei_pan_scan_rect(struct h264_syn *s,
 	if (s->err || r->pan_scan_rect_cancel_flag)
 		return;
 	f_ue(s, &r->pan_scan_cnt_minus1);
-	require(s, r->pan_scan_cnt_minus1 <= H264_ARRAY_SIZE(r->pan_scan_rect));
+	require(s, r->pan_scan_cnt_minus1 < H264_ARRAY_SIZE(r->pan_scan_rect));
 	for (i = 0; !s->err && i <= r->pan_scan_cnt_minus1; i++) {
 		f_se(s, &r->pan_scan_rect[i].left_offset);
 		f_se(s, &r->pan_scan_rect[i].right_offset);

@@ -78,6 +78,10 @@ int orc_bs_read_ue(struct h264_bitstream *bs, uint32_t *v)
 		if (orc_bs_read_bits(bs, &bit, lz) < 0)
 			return -EIO;
 	}
+	/* 32 leading zeros: the value does not fit 32 bits and the reference's
+	 * "1 << 32" is undefined; an error here as in the kernels */
+	if (lz >= 32)
+		return -EIO;
 	*v = (1u << lz) - 1 + bit;
 	return lz * 2 + 1;
 }

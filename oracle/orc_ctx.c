@@ -52,8 +52,11 @@ int orc_get_sps_derived(const struct h264_sps *sps, struct h264_sps_derived *d)
 	d->QpBdOffsetChroma = 6 * sps->bit_depth_chroma_minus8;
 	d->RawMbBits = 256 * d->BitDepthLuma +
 		       2 * d->MbWidthC * d->MbHeightC * d->BitDepthChroma;
-	d->MaxFrameNum = 1u << (sps->log2_max_frame_num_minus4 + 4);
-	d->MaxPicOrderCntLsb = 1u << (sps->log2_max_pic_order_cnt_lsb_minus4 + 4);
+	/* out-of-range exponents: shift count taken mod 32 like the x86 code the
+	 * reference compiles to, without the undefined behaviour */
+	d->MaxFrameNum = 1u << ((sps->log2_max_frame_num_minus4 + 4) & 31u);
+	d->MaxPicOrderCntLsb =
+		1u << ((sps->log2_max_pic_order_cnt_lsb_minus4 + 4) & 31u);
 	d->PicWidthInMbs = sps->pic_width_in_mbs_minus1 + 1;
 	d->PicWidthInSamplesLuma = 16 * d->PicWidthInMbs;
 	d->PicWidthInSamplesChroma = d->PicWidthInMbs * d->MbWidthC;

@@ -90,8 +90,12 @@ static int syn_hrd(struct h264_bitstream *bs, int wr, struct h264_hrd *h)
 	F_UE(h->cpb_cnt_minus1);
 	F_U(h->bit_rate_scale, 4);
 	F_U(h->cpb_size_scale, 4);
-	/* the reference's bound is off by one (Appendix C.8): 32 passes */
-	if (h->cpb_cnt_minus1 > NELEM(h->cpb))
+	/* MEMORY SAFETY, deliberate deviation: the reference tests "> ARRAY_SIZE"
+	 * here and at five more places (src/h264_syntax.h:43, :545, :566, :688,
+	 * PPS slice-group arrays), so a count equal to the array size writes one
+	 * element past the array (cpb_cnt_minus1 = 32 is outside the standard's
+	 * range 0..31 anyway).  Product and oracle reject it with -EIO. */
+	if (h->cpb_cnt_minus1 >= NELEM(h->cpb))
 		return -EIO;
 	for (i = 0; i <= h->cpb_cnt_minus1; i++) {
 		F_UE(h->cpb[i].bit_rate_value_minus1);
@@ -312,7 +316,7 @@ static int syn_pps_body(struct h264_bitstream *bs, int wr,
 		F_UE(p->slice_group_map_type);
 		switch (p->slice_group_map_type) {
 		case 0:
-			if (p->num_slice_groups_minus1 >
+			if (p->num_slice_groups_minus1 >=
 			    NELEM(p->run_length_minus1))
 				return -EIO;
 			for (i = 0; i <= p->num_slice_groups_minus1; i++)
@@ -337,7 +341,7 @@ static int syn_pps_body(struct h264_bitstream *bs, int wr,
 		case 6:
 			F_UE(p->pic_size_in_map_units_minus1);
 			len = orc_intlog2(p->num_slice_groups_minus1 + 1);
-			if (p->pic_size_in_map_units_minus1 >
+			if (p->pic_size_in_map_units_minus1 >=
 			    NELEM(p->slice_group_id))
 				return -EIO;
 			for (i = 0; i <= p->pic_size_in_map_units_minus1; i++)
@@ -396,7 +400,7 @@ static int syn_sei_buffering_period(struct h264_bitstream *bs, int wr,
 	if (ctx->sps->vui.nal_hrd_parameters_present_flag) {
 		hrd = &ctx->sps->vui.nal_hrd;
 		n = hrd->initial_cpb_removal_delay_length_minus1 + 1;
-		if (hrd->cpb_cnt_minus1 > NELEM(s->nal_hrd_cpb))
+		if (hrd->cpb_cnt_minus1 >= NELEM(s->nal_hrd_cpb))
 			return -EIO;
 		for (i = 0; i <= hrd->cpb_cnt_minus1; i++) {
 			F_U(s->nal_hrd_cpb[i].initial_cpb_removal_delay, n);
@@ -407,7 +411,7 @@ static int syn_sei_buffering_period(struct h264_bitstream *bs, int wr,
 	if (ctx->sps->vui.vcl_hrd_parameters_present_flag) {
 		hrd = &ctx->sps->vui.vcl_hrd;
 		n = hrd->initial_cpb_removal_delay_length_minus1 + 1;
-		if (hrd->cpb_cnt_minus1 > NELEM(s->vcl_hrd_cpb))
+		if (hrd->cpb_cnt_minus1 >= NELEM(s->vcl_hrd_cpb))
 			return -EIO;
 		for (i = 0; i <= hrd->cpb_cnt_minus1; i++) {
 			F_U(s->vcl_hrd_cpb[i].initial_cpb_removal_delay, n);
@@ -490,7 +494,7 @@ static int syn_sei_pan_scan_rect(struct h264_bitstream *bs, int wr,
 	if (s->pan_scan_rect_cancel_flag)
 		return 0;
 	F_UE(s->pan_scan_cnt_minus1);
-	if (s->pan_scan_cnt_minus1 > NELEM(s->pan_scan_rect))
+	if (s->pan_scan_cnt_minus1 >= NELEM(s->pan_scan_rect))
 		return -EIO;
 	for (i = 0; i <= s->pan_scan_cnt_minus1; i++) {
 		F_SE(s->pan_scan_rect[i].left_offset);
