@@ -111,8 +111,10 @@ static inline int h264_bs_fetch(struct h264_bitstream *bs)
 {
 	const uint8_t *p = bs->cdata;
 	size_t o = bs->off;
-	int escaped = bs->emulation_prevention && o >= 2 && p[o] == 0x03 &&
-		      p[o - 1] == 0x00 && p[o - 2] == 0x00;
+	/* o < len first: the reference looks at p[o] even at the end of the buffer
+	 * (one byte past it); the outcome is -EIO either way */
+	int escaped = bs->emulation_prevention && o >= 2 && o < bs->len &&
+		      p[o] == 0x03 && p[o - 1] == 0x00 && p[o - 2] == 0x00;
 	if (escaped) {
 		if (o + 1 >= bs->len)
 			return -EIO;

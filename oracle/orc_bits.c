@@ -12,7 +12,9 @@
 /* ref include/h264/h264_bitstream.h:168-190 */
 int orc_bs_fetch(struct h264_bitstream *bs)
 {
-	if (bs->emulation_prevention && bs->off >= 2 &&
+	/* off < len first: the reference reads cdata[off] even at the end of the
+	 * buffer (one byte past it); the outcome is -EIO either way */
+	if (bs->emulation_prevention && bs->off >= 2 && bs->off < bs->len &&
 	    bs->cdata[bs->off - 2] == 0 && bs->cdata[bs->off - 1] == 0 &&
 	    bs->cdata[bs->off] == 3) {
 		/* escape byte: deliver the byte behind it; a trailing 03 is
