@@ -882,6 +882,11 @@ sd_slice_data(WaveBits &wb, const VlcTabs &vt, uint32_t cbp_map, uint32_t lane,
 		if (!is_i) {
 			uint32_t run;
 			RD_UE(run);
+			/* a run read across the end of the data (zero padding) is
+			 * the reference's -EIO on the ue itself: no skipped
+			 * macroblock may come out of it */
+			if (wb_overrun(wb))
+				return -EIO;
 			for (uint32_t r = 0; r < run; r++) {
 				if (mbidx >= mb_capacity)
 					return H264_AMD_E_MB_OVERFLOW;
@@ -890,8 +895,6 @@ sd_slice_data(WaveBits &wb, const VlcTabs &vt, uint32_t cbp_map, uint32_t lane,
 				mbidx++;
 				mb_count = mbidx;
 			}
-			if (wb_overrun(wb))
-				return -EIO;
 			if (run > 0 && !wb_more_rbsp_data(wb, lane))
 				break;
 		}
