@@ -709,14 +709,27 @@ __device__ __forceinline__ uint32_t sd_residual_block(WaveBits &wb, const VlcTab
 		}
 		code += first_adj;
 		first_adj = 0;
-		/* even code -> +(code + 2) / 2, odd -> -(code + 1) / 2 */
-		uint32_t neg = code & 1u;
-		int32_t val = (int32_t)((((code + 2u) >> 1) ^ (0u - neg)) + neg);
-		int32_t v16 = (int16_t)val; /* levelVal is int16_t in the ref */
-		lv = wb_setlane(lv, i, (uint32_t)v16 & 0xffffu, lane);
+		/* even code -> +(code + 2) / 2, odd -> -(code + 1) / 2.  The value
+		 * itself is only needed in lane i: it is formed on the vector unit
+		 * (the copy of `code` is made opaque so that the arithmetic stays
+		 * there); the scalar unit keeps just the magnitude for suffix_len */
+		uint32_t mag = (code + 2u) >> 1;
+		{
+			uint32_t cv = code;
+			asm("" : "+v"(cv));
+			uint32_t ng = cv & 1u;
+			uint32_t vv = ((((cv + 2u) >> 1) ^ (0u - ng)) + ng) & 0xffffu;
+			lv = lane == i ? vv : lv;
+		}
+		if (mag > 32767u) {
+			/* levelVal is int16_t in the reference: after an escape the
+			 * magnitude that drives suffix_len is the wrapped one */
+			uint32_t neg = code & 1u;
+			int32_t v16 = (int16_t)((mag ^ (0u - neg)) + neg);
+			mag = (uint32_t)(v16 < 0 ? -v16 : v16);
+		}
 		suffix_len = suffix_len ? suffix_len : 1u;
-		uint32_t a = (uint32_t)(v16 < 0 ? -v16 : v16);
-		suffix_len += (a > (3u << (suffix_len - 1u)) && suffix_len < 6u) ? 1u : 0u;
+		suffix_len += (mag > (3u << (suffix_len - 1u)) && suffix_len < 6u) ? 1u : 0u;
 	}
 	uint32_t zeros_left = 0;
 	if (tc < maxnum)
