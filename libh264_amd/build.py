@@ -66,7 +66,8 @@ def build_engine(force=False):
     out = os.path.join(LIB, "libh264_amd_engine.so")
     srcs = _tree(CSRC, INC)
     if force or _newer(out, srcs):
-        _run([_hipcc(), "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC",
+        opt = os.environ.get("H264_AMD_HIPCC_OPT", "-O3").split()
+        _run([_hipcc(), "--offload-arch=gfx950"] + opt + ["-std=c++17", "-fPIC",
               "-shared", "-Wno-unused-value", "-I" + INC, "-I" + CSRC,
               os.path.join(CSRC, "engine.hip"), "-o", out])
     return out

@@ -28,6 +28,12 @@ MIXES = {
     "pcm": dict(pm_pcm=1000),
     "bench": dict(pm_i16x16=280, pm_pcm=2, density=5, pm_escape=5,
                   pm_cbp_zero=50, pm_zero_pcm=100),
+    # inter slices (generic instantiation of the kernel)
+    "p_mid": dict(slice_type=5, idr=0, pm_skip=300, pm_intra_in_inter=100,
+                  pm_i16x16=300, density=5, frame_num=1),
+    "b_mid": dict(slice_type=6, idr=0, nal_ref_idc=0, pm_skip=300,
+                  pm_intra_in_inter=100, pm_i16x16=300, density=5,
+                  frame_num=1),
 }
 
 
