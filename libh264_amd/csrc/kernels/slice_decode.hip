@@ -1007,15 +1007,28 @@ sd_slice_data(WaveBits &wb, const VlcTabs &vt, uint32_t cbp_map, uint32_t lane,
 			uint32_t p = wb_pos(wb) & 7u;
 			if (p && wb_u(wb, lane, 8u - p) != 0)
 				return -EIO;
-			uint32_t total = 256u + 2u * S.pcm_chroma;
-			for (uint32_t k = 0; k < total; k++) {
-				if ((k & 15u) == 0) {
-					wb_sync(wb, lane);
-					if (wb_overrun(wb))
-						return -EIO;
-				}
-				uint32_t smp = wb_u(wb, lane, k < 256u ? S.bdl : S.bdc);
-				lds_w16(stage, H264_AMD_T2_HEAD + 2u * k, smp, lane);
+			/* 64 samples per step, one per lane: the sample counts (256
+			 * luma, 0 / 64 / 128 / 256 per chroma plane) are multiples of
+			 * 64, so a step is all luma or all chroma.  Lane k fetches the
+			 * two window dwords its sample straddles with a cross-lane
+			 * gather.  The window is 2048 bits, slides below bit 1024 and
+			 * a step spans at most 64 * 14 bits. */
+			const uint32_t total = 256u + 2u * S.pcm_chroma;
+			for (uint32_t k0 = 0; k0 < total; k0 += 64u) {
+				wb_sync(wb, lane);
+				if (wb_overrun(wb))
+					return -EIO;
+				const uint32_t bd = k0 < 256u ? S.bdl : S.bdc;
+				uint32_t off = wb.bitpos + lane * bd;
+				uint32_t hi = (uint32_t)__shfl((int)wb.wreg, (int)(off >> 5));
+				uint32_t lo = (uint32_t)__shfl((int)wb.wreg,
+							       (int)((off >> 5) + 1u));
+				uint64_t v = (((uint64_t)hi << 32) | lo) << (off & 31u);
+				uint32_t smp = (uint32_t)(v >> 32) >> (32u - bd);
+				*reinterpret_cast<uint16_t *>(
+					stage + H264_AMD_T2_HEAD + 2u * (k0 + lane)) =
+					(uint16_t)smp;
+				wb_skip(wb, 64u * bd);
 			}
 			m.cur = lane < 48 ? 16u : 0u;
 		} else {
