@@ -61,6 +61,7 @@ def main():
     from libh264_amd import gen, Params
     from libh264_amd.ctypes_abi import TIER_NONE
     import orc
+    import streams
     threads = min(len(os.sched_getaffinity(0)), 16)
     eng = libh264_amd.Engine(0)
 
@@ -123,6 +124,67 @@ def main():
         "achieved_GBps": round(2 * total / k_ms / 1e6, 1),
         "frac_of_hbm_peak": round(2 * total / k_ms / 1e6 / HBM_PEAK_GBS, 4)}),
         flush=True)
+    # ---- C3: CABAC P-slices ------------------------------------------------
+    # reader side: header + raw extent only (the reference has no CABAC
+    # decoder); writer side: h264_write_skipped_p_slice in CABAC, 8160 MBs
+    from libh264_amd.ctypes_abi import Sps, Pps, SliceHeader
+    sps, pps = Sps(), Pps()
+    sps.profile_idc, sps.level_idc, sps.chroma_format_idc = 100, 40, 1
+    sps.pic_order_cnt_type, sps.max_num_ref_frames = 2, 1
+    sps.pic_width_in_mbs_minus1, sps.pic_height_in_map_units_minus1 = 119, 67
+    sps.frame_mbs_only_flag = sps.direct_8x8_inference_flag = 1
+    pps.entropy_coding_mode_flag = 1
+    pps.deblocking_filter_control_present_flag = 1
+    pps.transform_8x8_mode_flag = 1
+    cparams = Params()
+    cparams.put_sps(sps)
+    cepoch = cparams.put_pps(pps)
+    n = args.slices
+    descs3, hdrs3 = [], []
+    for k in range(n):
+        sh = SliceHeader()
+        sh.slice_type = 5
+        sh.frame_num = k % 16
+        sh.slice_qp_delta = (k % 21) - 10
+        sh.cabac_init_idc = k % 3
+        descs3.append((1, cepoch, 8160, 2, 1))
+        hdrs3.append(sh)
+    got = eng.encode_synth(cparams, descs3, hdrs3, 1 << 10)
+    b = orc.Builder()
+    for k in range(0, n, max(1, n // 8)):
+        assert got[k] == b.nalu(2, 1, sps=sps, pps=pps, sh=hdrs3[k], kind=2,
+                                mb_count=8160), k
+    ms = []
+    for _ in range(args.reps):
+        eng.encode_synth(cparams, descs3, hdrs3, 1 << 10)
+        ms.append(eng.last_kernel_ms("synth"))
+    k_ms = float(np.median(ms))
+    print(json.dumps({
+        "kernel": "h264_amd_k_encode_synth", "workload": "C3 writer side: %d "
+        "all-skip CABAC P-slices of 8160 MBs" % n,
+        "kernel_ms": round(k_ms, 4),
+        "mmb_per_s": round(8160 * n / k_ms / 1e3, 1),
+        "bytes_out": int(sum(len(g) for g in got))}), flush=True)
+    # reader side on what was just written
+    buf3, offs3, sizes3 = streams.pack_nals(got)
+    d3 = eng.upload(buf3)
+    dd = [(int(o), int(s), cepoch) for o, s in zip(offs3, sizes3)]
+    out3 = eng.decode_slices(cparams, d3, dd, reader_flags=1, tier=TIER_NONE,
+                             want_headers=True)
+    r3 = eng.fetch_results(out3)
+    assert all(r3[k].status == 0 and (r3[k].flags & 4) and r3[k].mb_count == 0
+               for k in range(n))
+    ms = []
+    for _ in range(args.reps):
+        eng.decode_slices(cparams, d3, dd, reader_flags=1, tier=TIER_NONE,
+                          want_headers=True, outputs=out3)
+        ms.append(eng.last_kernel_ms("decode"))
+    k_ms = float(np.median(ms))
+    print(json.dumps({
+        "kernel": "h264_amd_k_decode_slices", "workload": "C3 reader side: %d "
+        "CABAC P-slices, header + raw extent (no CABAC decoder in the "
+        "reference)" % n, "kernel_ms": round(k_ms, 4),
+        "slices_per_s": round(n / k_ms * 1e3, 1)}), flush=True)
     eng.close()
 
 
