@@ -21,7 +21,18 @@
  *     (c) known answers the survey recorded from a real reference run
  *         (BASELINE.md section 2): struct sizes,
  *         SPS/PPS byte strings, synthetic-slice sizes -- tests/golden/.
+ *     (d) an independent CAVLC encoder (libh264_amd/csrc/gen) whose recorded
+ *         macroblock syntax must equal what this parser reads back
+ *         (tests/test_oracle_vs_generator.py), and the dense-CAVLC recipe of
+ *         SURVEY Appendix E with its reference-measured size.
  *   Everything else is restated from reading the source and is unpinned.
+ *
+ * DELIBERATE DEVIATIONS (memory safety, shared with the product): array
+ * counts equal to the array size are -EIO where the reference writes one
+ * element past the array (src/h264_syntax.h:43,545,566,688 and the PPS
+ * slice-group arrays); ue(v) with 32 or more leading zeros is -EIO instead of
+ * an undefined shift; the escape test never reads past the buffer end; MBAFF
+ * and slice groups return H264_AMD_E_UNSUPPORTED.
  *
  * All oracle symbols carry the orc_ prefix and operate on the public struct
  * types of include/h264/ so that records are byte-comparable with the product.
