@@ -12,18 +12,27 @@
  * with the reference's observable results (slice header struct, rawdata extent,
  * per-macroblock syntax, nz_coeff bookkeeping incl. its quirks, error points).
  *
- * Execution model: grid = number of slices, block = ONE wave (64 lanes).  The
- * parse state is wave-uniform and lives in SGPRs (see wave_bits.hip.h); the
- * lanes cooperate for
+ * Execution model: one slice per wave, SD_WAVES_PER_BLOCK waves per workgroup
+ * (they share the CAVLC tables in LDS and one barrier after staging them, and
+ * are independent afterwards); grid = slices / SD_WAVES_PER_BLOCK.  The parse
+ * state is wave-uniform and lives in SGPRs (see wave_bits.hip.h); the lanes
+ * cooperate for
  *   - ingesting/de-escaping the bitstream (coalesced loads, ballot compaction),
  *   - matching prefix codes (one candidate code word per lane, vlc_lanes.hip.h),
+ *   - the 16 intra prediction modes of a macroblock at once (pointer doubling,
+ *     sd_intra_pred_modes), I_PCM samples 64 at a time,
+ *   - runs of empty 4x4 blocks (prefix sum of code lengths over the blocks still
+ *     to come against the string of one bits at the cursor),
  *   - scattering run/level pairs of a 4x4 block into the record (lane i owns
  *     coefficient i; position = zerosLeft_i + TotalCoeff - 1 - i),
- *   - the nz_coeff neighbour context (lane = comp*16 + blkIdx, v_readlane),
+ *   - the nz_coeff neighbour context kept as running sums (lane = comp*16 +
+ *     blkIdx, struct MbCtx),
  *   - staging the macroblock record in LDS and writing it out with 16-byte
  *     stores, plus the order-independent checksum over it.
- * No MFMA: this is integer/bit work.  LDS per wave: 1 KiB RBSP ring + 4 KiB
- * record staging + 16 B per macroblock column of top-row nz context.
+ * No MFMA: this is integer/bit work.  LDS: 6.3 KiB of tables per workgroup; per
+ * wave 1 KiB RBSP ring + 4 KiB record staging + 16 B per macroblock column of
+ * top-row nz context.  Cost model and measurements:
+ * profiles/r01_decode_cost_model.md.
  *
  * Out of scope (status H264_AMD_E_UNSUPPORTED): MBAFF frames and slice groups.
  */
