@@ -175,3 +175,19 @@ def test_slice_paths_fail_loudly_without_gpu():
         assert fn(C.byref(bs), ctx, *args) == -19, fn
         assert bs.off == 0
     L.h264_ctx_destroy(ctx)
+
+
+def test_find_nalu_argument_checks():
+    """SURVEY Appendix C.15 (ref src/h264_bitstream.c:163-165)."""
+    L = prod.h264()
+    s, e = C.c_size_t(), C.c_size_t()
+    data = b"\x00\x00\x01\x65"
+    L.h264_find_nalu.argtypes = [C.c_void_p, C.c_size_t, C.c_void_p,
+                                 C.c_void_p]
+    assert L.h264_find_nalu(None, 4, C.byref(s), C.byref(e)) == -22
+    assert L.h264_find_nalu(data, 4, None, C.byref(e)) == -22
+    assert L.h264_find_nalu(data, 4, C.byref(s), None) == -22
+    # -EAGAIN: start found, no end marker; -ENOENT: no start code at all
+    assert L.h264_find_nalu(data, 4, C.byref(s), C.byref(e)) == -11
+    assert (s.value, e.value) == (3, 4)
+    assert L.h264_find_nalu(b"\x01\x02\x03", 3, C.byref(s), C.byref(e)) == -2
