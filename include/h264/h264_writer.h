@@ -3,7 +3,7 @@
  * the reference's include/h264/h264_writer.h:31-50).  There is no writer
  * object: every call serialises the NAL unit currently described by `ctx` into
  * the caller's bitstream, without a start code.  The batched, device-side
- * counterparts are h264_amd_rewrite_slices() / h264_amd_encode_skip_slices()
+ * counterparts are h264_amd_write_slices() / h264_amd_encode_synth_slices()
  * in <h264_amd.h>.
  */
 #ifndef _H264_WRITER_H_
