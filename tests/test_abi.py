@@ -127,3 +127,23 @@ def test_public_surface_equals_the_reference():
                                   "h264_dump_get_json_str", "h264_dump_nalu",
                                   "h264_dump_new"]
     assert sorted(mine - ref) == []
+
+
+def _layout(tmp_path, include_dir, tag):
+    exe = tmp_path / ("lp_" + tag)
+    subprocess.check_call(["gcc", "-std=gnu99", "-I" + include_dir,
+                           os.path.join(ROOT, "tests", "helpers",
+                                        "layout_probe.c"), "-o", str(exe)])
+    return subprocess.check_output([str(exe)], text=True)
+
+
+def test_struct_layout_field_by_field(tmp_path):
+    """99 sizeof / offsetof / enum probes of the public structs.  The expected
+    values (tests/golden/public_layout.txt) were printed by the same probe
+    compiled against the REFERENCE's headers; the drop-in's headers must give
+    the same, and so must the reference's whenever it is present."""
+    want = open(os.path.join(ROOT, "tests", "golden",
+                             "public_layout.txt")).read()
+    assert _layout(tmp_path, INC, "mine") == want
+    if os.path.isdir("/root/reference/include/h264"):
+        assert _layout(tmp_path, "/root/reference/include", "ref") == want
