@@ -512,8 +512,22 @@ extern "C" int h264_amd_decode_slices(struct h264_amd_engine *e,
 		return 0;
 	if (args->d_buf == NULL || args->d_descs == NULL || args->d_results == NULL)
 		return -EINVAL;
+	/* the kernel uses 16-byte vector stores for header images and T2 records
+	 * and dword accesses elsewhere: refuse what would fault on the device */
+	if (((uintptr_t)args->d_descs & 7u) || ((uintptr_t)args->d_results & 15u) ||
+	    ((uintptr_t)args->d_headers & 15u))
+		return -EINVAL;
 	uint32_t stride = args->mb_stride;
 	if (args->d_mb_out != NULL) {
+		if ((uintptr_t)args->d_mb_out & 15u)
+			return -EINVAL;
+		if (args->tier != H264_AMD_TIER_NONE && args->mb_capacity == 0)
+			return -EINVAL;
+		if ((uint64_t)args->n * args->mb_capacity * stride >
+		    (uint64_t)1 << 46)
+			return -E2BIG;
+		if (stride & 3u)
+			return -EINVAL;
 		if (args->tier == H264_AMD_TIER_T0 && stride < 4)
 			return -EINVAL;
 		if (args->tier == H264_AMD_TIER_T1 && stride < 64)

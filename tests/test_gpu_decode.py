@@ -111,3 +111,58 @@ def test_1080p_slice(engine):
     slices = [streams.rich_slice(cfg, 7, 7, pm_pcm=2, density=5,
                                  pm_escape=5, hdr_extras=0)]
     run_case(engine, cfg, slices, TIER_T2)
+
+
+def test_api_misuse_is_refused_on_the_host(engine):
+    """Bad pointers / strides must come back as -EINVAL from the entry point,
+    never reach the kernel (a faulting kernel can take the whole host's GPUs
+    down)."""
+    import ctypes as C
+    from libh264_amd import capi
+    from libh264_amd.ctypes_abi import DecodeArgs
+    L = capi.engine_lib()
+    cfg = streams.small_cfg()
+    nal = gen.slice_nal(cfg, streams.rich_slice(cfg, 1, 2))
+    ref = orc.parse_nalus([gen.sps(cfg), gen.pps(cfg), nal])
+    params = make_params(ref)
+    buf, offs, sizes = streams.pack_nals([nal])
+    d_buf = engine.upload(buf)
+    good = engine.decode_slices(params, d_buf, [(offs[0], sizes[0],
+                                                 params.epoch)],
+                                reader_flags=1, tier=TIER_T2, mb_capacity=64,
+                                want_headers=True)
+
+    def args(**kw):
+        a = DecodeArgs()
+        a.d_buf = d_buf.ptr
+        a.d_descs = good["d_descs"].ptr
+        a.n = 1
+        a.reader_flags = 1
+        a.tier = TIER_T2
+        a.mb_capacity = 64
+        a.d_results = good["results"].ptr
+        a.d_headers = good["headers"].ptr
+        a.d_mb_out = good["mb"].ptr
+        a.mb_stride = t2_stride(3)
+        for k, v in kw.items():
+            setattr(a, k, v)
+        return a
+
+    def call(a):
+        return L.h264_amd_decode_slices(engine.h, params.h, C.byref(a))
+
+    assert call(args()) == 0
+    assert call(args(d_buf=None)) == -22
+    assert call(args(d_results=good["results"].ptr.value + 4)) == -22
+    assert call(args(d_headers=good["headers"].ptr.value + 8)) == -22
+    assert call(args(d_mb_out=good["mb"].ptr.value + 4)) == -22
+    assert call(args(mb_stride=t2_stride(3) - 16)) == -22
+    assert call(args(mb_stride=t2_stride(3) + 4)) == -22
+    assert call(args(tier=7)) == -22
+    assert call(args(mb_capacity=0)) == -22
+    assert call(args(n=0)) == 0
+    assert L.h264_amd_decode_slices(None, params.h, C.byref(args())) == -22
+    assert L.h264_amd_decode_slices(engine.h, None, C.byref(args())) == -22
+    engine.sync()
+    res = engine.fetch_results(good)
+    assert res[0].status == 0
