@@ -166,3 +166,12 @@ def test_api_misuse_is_refused_on_the_host(engine):
     engine.sync()
     res = engine.fetch_results(good)
     assert res[0].status == 0
+
+
+def test_very_wide_picture(engine):
+    """300 macroblocks per row: the row context pushes the workgroup's LDS past
+    48 KiB (dynamic shared memory attribute path)."""
+    cfg = streams.small_cfg(width_mbs=300, height_mbs=3)
+    slices = [streams.rich_slice(cfg, 5, 2), streams.rich_slice(cfg, 6, 0),
+              streams.rich_slice(cfg, 7, 1, 299, 400)]
+    run_case(engine, cfg, slices, TIER_T2)
