@@ -191,3 +191,48 @@ def test_find_nalu_argument_checks():
     assert L.h264_find_nalu(data, 4, C.byref(s), C.byref(e)) == -11
     assert (s.value, e.value) == (3, 4)
     assert L.h264_find_nalu(b"\x01\x02\x03", 3, C.byref(s), C.byref(e)) == -2
+
+
+def test_sei_pic_timing_clock_conversion():
+    """h264_ctx_sei_pic_timing_to_ts / _to_us (ref src/h264_ctx.c:491-542):
+    ((h * 60 + m) * 60 + s) * time_scale + n_frames * num_units_in_tick *
+    (1 + nuit_field_based_flag) + time_offset, clamped at 0; us rounded."""
+    L = prod.h264()
+    from h264types import Sps
+
+    class Clk(C.Structure):
+        _fields_ = [(n, C.c_int32) for n in (
+            "clock_timestamp_flag ct_type nuit_field_based_flag counting_type "
+            "full_timestamp_flag discontinuity_flag cnt_dropped_flag n_frames "
+            "seconds_value minutes_value hours_value seconds_flag minutes_flag "
+            "hours_flag time_offset").split()]
+
+    class PicTiming(C.Structure):
+        _fields_ = [("cpb_removal_delay", C.c_uint32),
+                    ("dpb_output_delay", C.c_uint32),
+                    ("pic_struct", C.c_uint32), ("clk_ts", Clk * 3)]
+
+    assert C.sizeof(PicTiming) == 192
+    for f in (L.h264_ctx_sei_pic_timing_to_ts, L.h264_ctx_sei_pic_timing_to_us):
+        f.restype = C.c_uint64
+        f.argtypes = [C.c_void_p, C.POINTER(PicTiming)]
+    ctx = C.c_void_p()
+    L.h264_ctx_new(C.byref(ctx))
+    sps = Sps()
+    sps.vui_parameters_present_flag = 1
+    sps.vui.timing_info_present_flag = 1
+    sps.vui.num_units_in_tick = 1001
+    sps.vui.time_scale = 60000
+    L.h264_ctx_set_sps(ctx, C.byref(sps))
+    pt = PicTiming()
+    c = pt.clk_ts[0]
+    c.hours_value, c.minutes_value, c.seconds_value = 1, 2, 3
+    c.n_frames, c.nuit_field_based_flag, c.time_offset = 7, 1, -5
+    want = ((1 * 60 + 2) * 60 + 3) * 60000 + 7 * 1001 * 2 - 5
+    assert L.h264_ctx_sei_pic_timing_to_ts(ctx, C.byref(pt)) == want
+    assert L.h264_ctx_sei_pic_timing_to_us(ctx, C.byref(pt)) == \
+        (want * 1000000 + 30000) // 60000
+    c.hours_value = c.minutes_value = c.seconds_value = c.n_frames = 0
+    c.time_offset = -9  # would go negative: clamped to 0
+    assert L.h264_ctx_sei_pic_timing_to_ts(ctx, C.byref(pt)) == 0
+    L.h264_ctx_destroy(ctx)
