@@ -62,6 +62,7 @@ struct WaveBits {
 	uint32_t bitpos; /* bit position relative to base */
 	/* ---- per lane ---- */
 	uint32_t wreg; /* lane i: RBSP bytes base+4i.. as a big-endian word */
+	uint32_t wnext; /* lane i: wreg of lane i + 1 (one index serves a peek) */
 	uint32_t pre; /* raw dword of the next chunk (prefetch) */
 	/* ---- LDS ---- */
 	uint8_t *ring;
@@ -288,6 +289,7 @@ __device__ __forceinline__ void wb_refill(WaveBits &s)
 	WbFill r = wb_fill_slow(s.state, s.ring, s.pre, s.base, s.clean_total,
 				s.chunk);
 	s.wreg = r.wreg;
+	s.wnext = (uint32_t)__shfl_down((int)r.wreg, 1);
 	s.pre = r.pre;
 	s.clean_total = wb_uniform(r.clean_total);
 	s.chunk = wb_uniform(r.chunk);
@@ -378,7 +380,7 @@ __device__ __forceinline__ uint32_t wb_peek(WaveBits &s, uint32_t lane)
 	(void)lane;
 	uint32_t d = s.bitpos >> 5, sh = s.bitpos & 31u;
 	uint32_t hi = (uint32_t)__builtin_amdgcn_readlane((int)s.wreg, (int)d);
-	uint32_t lo = (uint32_t)__builtin_amdgcn_readlane((int)s.wreg, (int)d + 1);
+	uint32_t lo = (uint32_t)__builtin_amdgcn_readlane((int)s.wnext, (int)d);
 	uint64_t v = ((uint64_t)hi << 32) | lo;
 	uint32_t r = (uint32_t)((v << sh) >> 32);
 	/* opaque to the optimiser: comparisons of the result must stay 32-bit
