@@ -483,8 +483,11 @@ __device__ __forceinline__ uint32_t blk_at(uint32_t x, uint32_t y)
 	return (x & 1u) | ((y & 1u) << 1) | ((x >> 1) << 2) | ((y >> 1) << 3);
 }
 
-#define SD_INFO(nzlane, maxnum, cdc, coef)                                     \
-	((nzlane) | ((maxnum) << 6) | ((cdc) << 11) | ((coef) << 13))
+/* ctx: the lane whose table class applies; the block's own lane, except for
+ * chroma DC blocks, which use the constant classes parked in lanes 48 / 49 */
+#define SD_INFO(nzlane, maxnum, cdc, coef, ctx)                                \
+	((nzlane) | ((maxnum) << 6) | ((cdc) << 11) | ((coef) << 13) |         \
+	 ((ctx) << 24))
 
 /* Per-lane constants: neighbour geometry (6.4.11.4, as restated by the
  * reference in src/h264_slice_data.c:1239-1334) and, with lane = step, the
@@ -534,23 +537,26 @@ __device__ __forceinline__ void sd_mb_consts(MbCtx &m, uint32_t lane, uint32_t c
 	if (s < luma_steps) {
 		uint32_t c = s / 17u, sub = s % 17u;
 		if (sub == 0) {
-			in = ii = SD_INFO(16u * c, 16u, 0u, 256u * c);
+			in = ii = SD_INFO(16u * c, 16u, 0u, 256u * c, 16u * c);
 		} else {
 			uint32_t blk = sub - 1u;
-			in = SD_INFO(16u * c + blk, 16u, 0u, 256u * c + 16u * blk);
+			in = SD_INFO(16u * c + blk, 16u, 0u, 256u * c + 16u * blk,
+				     16u * c + blk);
 			ii = SD_INFO(16u * c + blk, 15u, 0u,
-				     256u * c + 16u + 15u * blk);
+				     256u * c + 16u + 15u * blk, 16u * c + blk);
 		}
 	} else if (cat == 1 || cat == 2) {
 		uint32_t c = s - luma_steps;
 		if (c < 2) {
-			in = SD_INFO(16u * (1u + c), nchroma, cat, 256u + nchroma * c);
+			in = SD_INFO(16u * (1u + c), nchroma, cat, 256u + nchroma * c,
+				     48u + c);
 		} else if (c < 2u + 2u * nchroma) {
 			c -= 2u;
 			uint32_t cc = c >= nchroma ? 1u : 0u;
 			uint32_t blk = c - cc * nchroma;
 			in = SD_INFO(16u * (1u + cc) + blk, 15u, 0u,
-				     256u + 2u * nchroma + 15u * (nchroma * cc + blk));
+				     256u + 2u * nchroma + 15u * (nchroma * cc + blk),
+				     16u * (1u + cc) + blk);
 		}
 		ii = in;
 	}
@@ -582,6 +588,15 @@ __device__ __forceinline__ uint32_t sd_nc_all(const MbCtx &m)
 __device__ __forceinline__ uint32_t sd_nc(const MbCtx &m, uint32_t l)
 {
 	return (uint32_t)__builtin_amdgcn_readlane((int)sd_nc_all(m), (int)l);
+}
+
+/* coeff_token table class of every block, per lane (vector unit); lanes 48 / 49
+ * hold the constant classes of the chroma DC blocks (3 + ChromaArrayType) */
+__device__ __forceinline__ uint32_t sd_class_all(const MbCtx &m, uint32_t lane,
+						 uint32_t cat)
+{
+	uint32_t c = vlc_ct_class(sd_nc_all(m));
+	return lane >= 48u ? 3u + cat : c;
 }
 
 /* block at lane l now has TotalCoeff tc (it may have had another value: the
@@ -671,12 +686,12 @@ __device__ __forceinline__ uint32_t sd_scan_add(uint32_t x)
  * walk goes on with benign values until the caller looks at it. */
 __device__ __forceinline__ uint32_t sd_residual_block(WaveBits &wb, const VlcTabs &vt,
 						      uint32_t lane, uint8_t *stage,
-						      uint32_t nC, uint32_t chroma_dc,
+						      uint32_t cls,
 						      uint32_t maxnum, uint32_t coef_off,
 						      uint32_t &tc_out)
 {
 	uint32_t t1, tc;
-	uint32_t err = vlc_coeff_token(vt, wb, lane, nC, chroma_dc, t1, tc);
+	uint32_t err = vlc_coeff_token(vt, wb, lane, cls, t1, tc);
 	tc_out = tc;
 	if (tc == 0)
 		return err;
@@ -1263,10 +1278,13 @@ sd_slice_data(WaveBits &wb, const VlcTabs &vt, uint32_t cbp_map, uint32_t lane,
 						(int)vinfo, (int)step);
 					uint32_t nzlane = info & 63u;
 					uint32_t tc;
+					uint32_t cls = (uint32_t)__builtin_amdgcn_readlane(
+						(int)sd_class_all(m, lane, cat),
+						(int)(info >> 24));
 					err |= sd_residual_block(
-						wb, vt, lane, stage, sd_nc(m, nzlane),
-						(info >> 11) & 3u, (info >> 6) & 31u,
-						info >> 13, tc);
+						wb, vt, lane, stage, cls,
+						(info >> 6) & 31u,
+						(info >> 13) & 0x7ffu, tc);
 					/* TotalCoeff is recorded for every class, DC
 					 * blocks included (Appendix C.4) */
 					sd_nz_set(m, nzlane, tc, lane);

@@ -91,17 +91,21 @@ __device__ __forceinline__ uint32_t vlc_match(const uint8_t *row, uint32_t off,
 	return (uint32_t)__builtin_amdgcn_readlane((int)e.y, hit & 63);
 }
 
-/* coeff_token.  chroma_dc: 0 no, 1 4:2:0 (nC = -1), 2 4:2:2 (nC = -2).
- * Returns the bad flag. */
+/* class of coeff_token table for nC = 0..8+: 0 0 1 1 2 2 2 2 3, two bits each
+ * (works on scalars and per lane alike) */
+__device__ __forceinline__ uint32_t vlc_ct_class(uint32_t nC)
+{
+	uint32_t c = nC < 8u ? nC : 8u;
+	return (0x3AA50u >> (2u * c)) & 3u;
+}
+
+/* coeff_token with the table class `cls` (0..3 by nC, 4 / 5 chroma DC 4:2:0 /
+ * 4:2:2).  Returns the bad flag. */
 __device__ __forceinline__ uint32_t vlc_coeff_token(const VlcTabs &t, WaveBits &s,
-						    uint32_t lane, uint32_t nC,
-						    uint32_t chroma_dc, uint32_t &t1,
-						    uint32_t &tc)
+						    uint32_t lane, uint32_t cls,
+						    uint32_t &t1, uint32_t &tc)
 {
 	uint32_t bits = wb_peek(s, lane);
-	/* class of nC = 0..8+: 0 0 1 1 2 2 2 2 3, two bits each */
-	uint32_t c = nC < 8u ? nC : 8u;
-	uint32_t cls = chroma_dc ? 3u + chroma_dc : (0x3AA50u >> (2u * c)) & 3u;
 	uint32_t bad;
 	int hit;
 	uint32_t cw = vlc_match(t.ct + 512u * cls, t.off64, bits, bad, hit);
