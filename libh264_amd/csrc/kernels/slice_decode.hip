@@ -604,12 +604,12 @@ __device__ __forceinline__ uint32_t sd_class_all(const MbCtx &m, uint32_t lane,
 __device__ __forceinline__ void sd_nz_set(MbCtx &m, uint32_t l, uint32_t tc,
 					  uint32_t lane)
 {
+	/* unconditional: a handful of vector instructions instead of a scalar
+	 * compare and branch (the scalar port is the scarce one) */
 	uint32_t old = (uint32_t)__builtin_amdgcn_readlane((int)m.cur, (int)l);
-	if (tc != old) {
-		uint32_t delta = tc - old;
-		m.cur = lane == l ? tc : m.cur;
-		m.sum += (m.a_int == l ? delta : 0u) + (m.b_int == l ? delta : 0u);
-	}
+	uint32_t delta = tc - old;
+	m.cur = lane == l ? tc : m.cur;
+	m.sum += (m.a_int == l ? delta : 0u) + (m.b_int == l ? delta : 0u);
 }
 
 /* The n (16 or 4) prev_intra_pred_mode_flag / rem_intra_pred_mode pairs of an
