@@ -127,6 +127,10 @@ static inline uint32_t h264_amd_t2_stride(uint32_t chroma_array_type)
 /* Engine-specific status values besides negative errno */
 #define H264_AMD_E_UNSUPPORTED (-ENOSYS) /* MBAFF / FMO: out of scope */
 #define H264_AMD_E_MB_OVERFLOW (-EOVERFLOW) /* more MBs than mb_capacity */
+/* Most macroblocks one slice may deliver (64 pictures of 4096 x 2304): where the
+ * drop-in reader stops growing a slice's record area, and where the oracle
+ * stops too.  Only a damaged mb_skip_run gets anywhere near. */
+#define H264_AMD_MAX_SLICE_MBS (1u << 22)
 
 /* Per-slice outcome, 64 bytes.  status mirrors what _h264_read_nalu would
  * have returned for this NAL (0, -EIO, -EINVAL ...). */

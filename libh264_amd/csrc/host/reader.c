@@ -348,7 +348,7 @@ static int batch_fetch(struct h264_reader *rd, struct rd_batch *b, size_t idx)
  * the room until it fits.  RD_MAX_MB_CAP bounds what a corrupt mb_skip_run can
  * ask for (the reference would call back 2^32 times); beyond it the slice
  * fails with -EOVERFLOW. */
-#define RD_MAX_MB_CAP (1u << 22)
+#define RD_MAX_MB_CAP H264_AMD_MAX_SLICE_MBS
 
 static int retry_big_slice(struct h264_reader *rd, struct rd_batch *b,
 			   size_t slice, struct h264_amd_slice_result *r,

@@ -413,15 +413,17 @@ __device__ __forceinline__ uint32_t wb_u1(WaveBits &s, uint32_t lane)
 __device__ __forceinline__ uint32_t wb_ue(WaveBits &s, uint32_t lane, bool &ok)
 {
 	uint32_t v = wb_peek(s, lane);
+	if (v >= 0x10000u) {
+		/* at most 15 leading zeros: the whole code is in the peek */
+		uint32_t lz = (uint32_t)__builtin_clz(v);
+		wb_skip(s, 2 * lz + 1);
+		return (v >> (31u - 2u * lz)) - 1u;
+	}
 	if (v == 0) {
 		ok = false;
 		return 0;
 	}
 	uint32_t lz = (uint32_t)__builtin_clz(v);
-	if (lz <= 15) {
-		wb_skip(s, 2 * lz + 1);
-		return (v >> (31u - 2u * lz)) - 1u;
-	}
 	wb_skip(s, lz);
 	uint32_t u = wb_peek(s, lane);
 	wb_skip(s, lz + 1);

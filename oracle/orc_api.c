@@ -82,6 +82,7 @@ int orc_reader_parse(struct orc_reader *rd, uint32_t flags, const uint8_t *buf,
 
 #define ORC_REC_WANT_T2 0x1 /* keep a T2 record per macroblock */
 #define ORC_REC_WANT_REWRITE 0x2 /* h264-dump style write-back check */
+#define ORC_REC_T2_CAP 65536u
 
 struct orc_rewrite {
 	uint64_t off; /* into rewrites blob */
@@ -197,7 +198,9 @@ static void cb_sd_mb(struct orc_ctx *ctx, const struct h264_slice_header *sh,
 				h264_amd_checksum_term(r->cur_mbs * 1024u + i,
 						       w[i]));
 	}
-	if (r->want & ORC_REC_WANT_T2)
+	/* full records only for the first ORC_REC_T2_CAP macroblocks of a slice:
+	 * a damaged skip run would otherwise cost a KiB per phantom macroblock */
+	if ((r->want & ORC_REC_WANT_T2) && r->cur_mbs < ORC_REC_T2_CAP)
 		evvec_push(&r->mbrecs, tmp, stride);
 	r->cur_mbs++;
 }

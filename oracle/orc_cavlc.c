@@ -979,6 +979,11 @@ static int slice_data_internal(struct h264_bitstream *bs, struct orc_reader *rd)
 		    ctx->slice.type != H264_SLICE_TYPE_SI) {
 			CHK(orc_bs_read_ue(bs, &skip_run));
 			for (i = 0; i < skip_run; i++) {
+				/* a damaged mb_skip_run can ask for 2^32
+				 * macroblocks (and the table for them): product
+				 * and oracle stop at H264_AMD_MAX_SLICE_MBS */
+				if (mb_count >= H264_AMD_MAX_SLICE_MBS)
+					return H264_AMD_E_MB_OVERFLOW;
 				CHK(orc_new_macroblock(ctx, addr, 1, -1));
 				if (rd->cbs.slice_data_mb)
 					rd->cbs.slice_data_mb(ctx, sh,
@@ -991,6 +996,8 @@ static int slice_data_internal(struct h264_bitstream *bs, struct orc_reader *rd)
 			if (skip_run > 0 && !orc_bs_more_rbsp_data(bs))
 				break;
 		}
+		if (mb_count >= H264_AMD_MAX_SLICE_MBS)
+			return H264_AMD_E_MB_OVERFLOW;
 		CHK(orc_new_macroblock(ctx, addr, 0, -1));
 		res = macroblock_layer(bs, ctx, ctx->mb);
 		if (res < 0)

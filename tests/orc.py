@@ -107,9 +107,12 @@ class Recording:
         r = self.results[slice_index]
         stride = t2_stride(r.chroma_array_type)
         off = self.mboffs[slice_index]
-        a = np.frombuffer(self.mbrecs, dtype=np.uint8,
-                          count=r.mb_count * stride, offset=off)
-        return a.reshape(r.mb_count, stride)
+        # the recorder keeps full records for the first 65536 macroblocks of a
+        # slice only (ORC_REC_T2_CAP: a damaged skip run can produce millions)
+        n = min(r.mb_count, 65536)
+        a = np.frombuffer(self.mbrecs, dtype=np.uint8, count=n * stride,
+                          offset=off)
+        return a.reshape(n, stride)
 
 
 def parse_stream(data, flags=READER_FLAGS_SLICE_DATA, want=ORC_REC_WANT_T2):
