@@ -79,6 +79,10 @@ def one(engine, seed):
 
 
 def main():
+    # never let a run-away input take the whole box down: cap our own address
+    # space well below the machine's memory
+    import resource
+    resource.setrlimit(resource.RLIMIT_AS, (96 << 30, 96 << 30))
     first = int(sys.argv[1]) if len(sys.argv) > 1 else 100
     count = int(sys.argv[2]) if len(sys.argv) > 2 else 20
     eng = libh264_amd.Engine(0)
