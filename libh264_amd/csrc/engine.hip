@@ -389,19 +389,20 @@ extern "C" int h264_amd_params_put_sps(struct h264_amd_params *p,
 		return -ENOSPC;
 	dev_sps d;
 	memset(&d, 0, sizeof(d));
-	d.chroma_format_idc = (uint8_t)sps->chroma_format_idc;
-	d.separate_colour_plane_flag = (uint8_t)sps->separate_colour_plane_flag;
-	d.bit_depth_luma = (uint8_t)(8 + sps->bit_depth_luma_minus8);
-	d.bit_depth_chroma = (uint8_t)(8 + sps->bit_depth_chroma_minus8);
-	d.log2_max_frame_num = (uint8_t)(4 + sps->log2_max_frame_num_minus4);
-	d.pic_order_cnt_type = (uint8_t)sps->pic_order_cnt_type;
-	d.log2_max_pic_order_cnt_lsb =
-		(uint8_t)(4 + sps->log2_max_pic_order_cnt_lsb_minus4);
+	d.chroma_format_idc = DEV_SAT8(sps->chroma_format_idc);
+	d.separate_colour_plane_flag = (uint8_t)(sps->separate_colour_plane_flag != 0);
+	/* the SPS parser refuses minus8 > 6; a hand-built SPS beyond that gets
+	 * memory-safe garbage samples */
+	d.bit_depth_luma = DEV_SAT8(8u + sps->bit_depth_luma_minus8);
+	d.bit_depth_chroma = DEV_SAT8(8u + sps->bit_depth_chroma_minus8);
+	d.log2_max_frame_num = 4u + sps->log2_max_frame_num_minus4;
+	d.pic_order_cnt_type = DEV_SAT8(sps->pic_order_cnt_type);
+	d.log2_max_pic_order_cnt_lsb = 4u + sps->log2_max_pic_order_cnt_lsb_minus4;
 	d.delta_pic_order_always_zero_flag =
-		(uint8_t)sps->delta_pic_order_always_zero_flag;
-	d.frame_mbs_only_flag = (uint8_t)sps->frame_mbs_only_flag;
-	d.mb_adaptive_frame_field_flag = (uint8_t)sps->mb_adaptive_frame_field_flag;
-	d.direct_8x8_inference_flag = (uint8_t)sps->direct_8x8_inference_flag;
+		(uint8_t)(sps->delta_pic_order_always_zero_flag != 0);
+	d.frame_mbs_only_flag = (uint8_t)(sps->frame_mbs_only_flag != 0);
+	d.mb_adaptive_frame_field_flag = (uint8_t)(sps->mb_adaptive_frame_field_flag != 0);
+	d.direct_8x8_inference_flag = (uint8_t)(sps->direct_8x8_inference_flag != 0);
 	d.pic_width_in_mbs = sps->pic_width_in_mbs_minus1 + 1;
 	d.pic_height_in_map_units = sps->pic_height_in_map_units_minus1 + 1;
 	p->sps_full.push_back(*sps);
@@ -432,22 +433,20 @@ extern "C" int h264_amd_params_put_pps(struct h264_amd_params *p,
 		return -ENOSPC;
 	dev_pps d;
 	memset(&d, 0, sizeof(d));
-	d.seq_parameter_set_id = (uint8_t)(pps->seq_parameter_set_id < 255
-						   ? pps->seq_parameter_set_id
-						   : 255);
-	d.entropy_coding_mode_flag = (uint8_t)pps->entropy_coding_mode_flag;
+	d.seq_parameter_set_id = DEV_SAT8(pps->seq_parameter_set_id);
+	d.entropy_coding_mode_flag = (uint8_t)(pps->entropy_coding_mode_flag != 0);
 	d.bottom_field_pic_order_in_frame_present_flag =
-		(uint8_t)pps->bottom_field_pic_order_in_frame_present_flag;
-	d.num_slice_groups_minus1 = (uint8_t)pps->num_slice_groups_minus1;
-	d.slice_group_map_type = (uint8_t)pps->slice_group_map_type;
-	d.weighted_pred_flag = (uint8_t)pps->weighted_pred_flag;
-	d.weighted_bipred_idc = (uint8_t)pps->weighted_bipred_idc;
+		(uint8_t)(pps->bottom_field_pic_order_in_frame_present_flag != 0);
+	d.num_slice_groups_minus1 = DEV_SAT8(pps->num_slice_groups_minus1);
+	d.slice_group_map_type = DEV_SAT8(pps->slice_group_map_type);
+	d.weighted_pred_flag = (uint8_t)(pps->weighted_pred_flag != 0);
+	d.weighted_bipred_idc = DEV_SAT8(pps->weighted_bipred_idc);
 	d.deblocking_filter_control_present_flag =
-		(uint8_t)pps->deblocking_filter_control_present_flag;
+		(uint8_t)(pps->deblocking_filter_control_present_flag != 0);
 	d.redundant_pic_cnt_present_flag =
-		(uint8_t)pps->redundant_pic_cnt_present_flag;
-	d.transform_8x8_mode_flag = (uint8_t)pps->transform_8x8_mode_flag;
-	d.constrained_intra_pred_flag = (uint8_t)pps->constrained_intra_pred_flag;
+		(uint8_t)(pps->redundant_pic_cnt_present_flag != 0);
+	d.transform_8x8_mode_flag = (uint8_t)(pps->transform_8x8_mode_flag != 0);
+	d.constrained_intra_pred_flag = (uint8_t)(pps->constrained_intra_pred_flag != 0);
 	d.pic_init_qp_minus26 = pps->pic_init_qp_minus26;
 	d.pic_init_qs_minus26 = pps->pic_init_qs_minus26;
 	d.num_ref_idx_l0_default_active_minus1 =

@@ -104,6 +104,24 @@ static void bw_u(struct bw *w, uint32_t v, int n)
 	}
 }
 
+/* a field whose width comes from the SPS: any 32-bit width.  Above 32 bits the
+ * value is preceded by zeros (what the reference's writer produces for a
+ * 32-bit field); above 40000 bits only 2048 zero bits are written, which makes
+ * the slice too short on purpose (hostile-SPS tests). */
+static void bw_u_wide(struct bw *w, uint32_t v, uint32_t n)
+{
+	uint32_t z;
+	if (n > 40000) {
+		for (z = 0; z < 2048; z += 32)
+			bw_u(w, 0, 32);
+		return;
+	}
+	for (z = n > 32 ? n - 32 : 0; z > 0; z -= z < 32 ? z : 32)
+		bw_u(w, 0, z < 32 ? (int)z : 32);
+	if (n)
+		bw_u(w, v, n < 32 ? (int)n : 32);
+}
+
 static void bw_ue(struct bw *w, uint32_t v)
 {
 	uint32_t x = v + 1;
@@ -878,11 +896,11 @@ static void put_slice_header(struct gen *g)
 	bw_ue(w, s->first_mb);
 	bw_ue(w, s->slice_type);
 	bw_ue(w, c->pps_id);
-	bw_u(w, s->frame_num, (int)c->log2_max_frame_num_minus4 + 4);
+	bw_u_wide(w, s->frame_num, c->log2_max_frame_num_minus4 + 4u);
 	if (s->idr)
 		bw_ue(w, s->idr_pic_id);
 	if (c->pic_order_cnt_type == 0) {
-		bw_u(w, s->poc_lsb, (int)c->log2_max_poc_lsb_minus4 + 4);
+		bw_u_wide(w, s->poc_lsb, c->log2_max_poc_lsb_minus4 + 4u);
 		if (c->bottom_field_pic_order_in_frame_present_flag)
 			bw_se(w, 0);
 	}
@@ -987,7 +1005,7 @@ size_t h264gen_slice_bound(const struct h264gen_cfg *cfg,
 		per_mb = 48 * 16 * 2 + 256; /* dense small levels */
 	else if (sl->pm_pcm == 0)
 		per_mb = 48 * 16 * 6 + 256;
-	return 1024 + (size_t)sl->num_mbs * per_mb + sl->cabac_payload * 2;
+	return 12288 + (size_t)sl->num_mbs * per_mb + sl->cabac_payload * 2;
 }
 
 int h264gen_slice_nal(const struct h264gen_cfg *cfg,

@@ -16,32 +16,38 @@
 
 #define DEV_NO_VERSION 0xffffu
 
-/* fields of struct h264_sps the slice kernels read (32 bytes) */
+/* fields of struct h264_sps the slice kernels read (32 bytes).  The reference
+ * range-checks almost nothing in an SPS/PPS (src/h264_syntax.h:278-345), so a
+ * damaged parameter set can carry any 32-bit value: byte fields that are only
+ * compared with small constants SATURATE at 255 (DEV_SAT8), field widths keep
+ * all 32 bits (a u(n) with n > 32 is legal for the reference's reader,
+ * include/h264/h264_bitstream.h:192-218). */
 struct dev_sps {
-	uint8_t chroma_format_idc;
+	uint8_t chroma_format_idc; /* saturating */
 	uint8_t separate_colour_plane_flag;
-	uint8_t bit_depth_luma; /* 8..14 */
+	uint8_t bit_depth_luma; /* 8..14, checked by the SPS parser */
 	uint8_t bit_depth_chroma;
-	uint8_t log2_max_frame_num; /* 4..16 */
-	uint8_t pic_order_cnt_type;
-	uint8_t log2_max_pic_order_cnt_lsb;
+	uint8_t pic_order_cnt_type; /* saturating */
 	uint8_t delta_pic_order_always_zero_flag;
 	uint8_t frame_mbs_only_flag;
 	uint8_t mb_adaptive_frame_field_flag;
 	uint8_t direct_8x8_inference_flag;
-	uint8_t pad0;
+	uint8_t pad0[3];
 	uint32_t pic_width_in_mbs;
 	uint32_t pic_height_in_map_units;
-	uint32_t pad1[3];
+	uint32_t log2_max_frame_num; /* 4 + minus4, modulo 2^32 like the reference */
+	uint32_t log2_max_pic_order_cnt_lsb;
+	uint32_t pad1;
 };
+#define DEV_SAT8(x) ((uint8_t)((x) < 255u ? (x) : 255u))
 
 /* fields of struct h264_pps the slice kernels read (32 bytes) */
 struct dev_pps {
 	uint8_t seq_parameter_set_id;
 	uint8_t entropy_coding_mode_flag;
 	uint8_t bottom_field_pic_order_in_frame_present_flag;
-	uint8_t num_slice_groups_minus1;
-	uint8_t slice_group_map_type;
+	uint8_t num_slice_groups_minus1; /* saturating */
+	uint8_t slice_group_map_type; /* saturating */
 	uint8_t weighted_pred_flag;
 	uint8_t weighted_bipred_idc;
 	uint8_t deblocking_filter_control_present_flag;

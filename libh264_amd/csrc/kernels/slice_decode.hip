@@ -268,7 +268,9 @@ sd_slice_header(WaveBits &wb, uint32_t lane, uint8_t *stage, SliceState &S,
 		v = wb_u(wb, lane, 2);
 		HP(colour_plane_id, v);
 	}
-	v = wb_u(wb, lane, sps.log2_max_frame_num);
+	v = wb_u_any(wb, lane, sps.log2_max_frame_num, ok);
+	if (!ok)
+		return -EIO;
 	HP(frame_num, v);
 	if (!sps.frame_mbs_only_flag) {
 		field_pic = wb_u1(wb, lane);
@@ -284,7 +286,9 @@ sd_slice_header(WaveBits &wb, uint32_t lane, uint8_t *stage, SliceState &S,
 	}
 	wb_sync(wb, lane);
 	if (sps.pic_order_cnt_type == 0) {
-		v = wb_u(wb, lane, sps.log2_max_pic_order_cnt_lsb);
+		v = wb_u_any(wb, lane, sps.log2_max_pic_order_cnt_lsb, ok);
+		if (!ok)
+			return -EIO;
 		HP(pic_order_cnt_lsb, v);
 		if (pps.bottom_field_pic_order_in_frame_present_flag && !field_pic) {
 			RD_SE(sv);

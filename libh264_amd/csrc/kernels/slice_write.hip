@@ -155,6 +155,22 @@ __device__ __forceinline__ void bw_u(BitW &w, uint32_t v, uint32_t n,
 	}
 }
 
+/* u(n) for any n, as the reference's writer behaves for a width taken from a
+ * damaged SPS (src/h264_bitstream.c:210-240): the value is a 32-bit field
+ * widened to 64 bits, so bits above 32 are zeros; n > 64 is refused (-EINVAL). */
+__device__ __forceinline__ int bw_u_any(BitW &w, uint32_t v, uint32_t n,
+					uint32_t lane)
+{
+	if (n > 64)
+		return -EINVAL;
+	if (n > 32) {
+		bw_u(w, 0, n - 32u, lane);
+		n = 32;
+	}
+	bw_u(w, v, n, lane);
+	return 0;
+}
+
 /* ue(v) as the reference writes it (ref src/h264_bitstream.c:245-287): v + 1
  * on 2 * bits - 1 bits; v = 0xffffffff wraps to a single 0 bit there too */
 __device__ __forceinline__ void bw_ue(BitW &w, uint32_t v, uint32_t lane)
@@ -269,7 +285,8 @@ __device__ __forceinline__ int sw_slice_header(BitW &w, const uint8_t *hdr,
 	bw_ue(w, HG(pic_parameter_set_id), lane);
 	if (sps.separate_colour_plane_flag)
 		bw_u(w, HG(colour_plane_id), 2, lane);
-	bw_u(w, HG(frame_num), sps.log2_max_frame_num, lane);
+	if (bw_u_any(w, HG(frame_num), sps.log2_max_frame_num, lane))
+		return -EINVAL;
 	uint32_t field_pic = 0;
 	if (!sps.frame_mbs_only_flag) {
 		field_pic = HG(field_pic_flag);
@@ -280,7 +297,9 @@ __device__ __forceinline__ int sw_slice_header(BitW &w, const uint8_t *hdr,
 	if (nal_unit_type == 5)
 		bw_ue(w, HG(idr_pic_id), lane);
 	if (sps.pic_order_cnt_type == 0) {
-		bw_u(w, HG(pic_order_cnt_lsb), sps.log2_max_pic_order_cnt_lsb, lane);
+		if (bw_u_any(w, HG(pic_order_cnt_lsb), sps.log2_max_pic_order_cnt_lsb,
+			     lane))
+			return -EINVAL;
 		if (pps.bottom_field_pic_order_in_frame_present_flag && !field_pic)
 			bw_se(w, (int32_t)HG(delta_pic_order_cnt_bottom), lane);
 	}

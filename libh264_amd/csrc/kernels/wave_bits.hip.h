@@ -403,6 +403,34 @@ __device__ __forceinline__ uint32_t wb_u(WaveBits &s, uint32_t lane, uint32_t n)
 	return v >> (32u - n);
 }
 
+/* u(n) for ANY n, as the reference's reader behaves when a damaged parameter
+ * set hands it a width outside 1..32 (include/h264/h264_bitstream.h:192-218):
+ * n == 0 reads nothing and yields 0; n > 32 consumes all n bits and keeps the
+ * last 32.  ok is cleared when the NAL cannot hold that many bits (the
+ * reference runs out of data: -EIO); shorter overruns are caught lazily like
+ * everywhere else.  Cold: only field widths taken from an SPS come here. */
+__device__ __forceinline__ uint32_t wb_u_any(WaveBits &s, uint32_t lane,
+					     uint32_t n, bool &ok)
+{
+	if (n == 0)
+		return 0;
+	if (n > 32) {
+		uint32_t extra = n - 32u;
+		if ((uint64_t)extra > (uint64_t)s.len * 8u) {
+			ok = false;
+			return 0;
+		}
+		while (extra) {
+			uint32_t k = extra < 512u ? extra : 512u;
+			wb_skip(s, k);
+			wb_sync(s, lane);
+			extra -= k;
+		}
+		n = 32;
+	}
+	return wb_u(s, lane, n);
+}
+
 __device__ __forceinline__ uint32_t wb_u1(WaveBits &s, uint32_t lane)
 {
 	return wb_u(s, lane, 1);

@@ -175,3 +175,75 @@ def test_very_wide_picture(engine):
     slices = [streams.rich_slice(cfg, 5, 2), streams.rich_slice(cfg, 6, 0),
               streams.rich_slice(cfg, 7, 1, 299, 400)]
     run_case(engine, cfg, slices, TIER_T2)
+
+
+@pytest.mark.parametrize("fn4,poc4", [
+    (28, 2),            # 32-bit frame_num
+    (29, 28),           # 33 / 32 bits: the value is preceded by a zero
+    (60, 29),           # 64 / 33 bits
+    (61, 2),            # 65 bits: parses, cannot be written back (-EINVAL)
+    (2, 61),
+    (300, 2),           # low byte of the width would be 48
+    (130560, 2),        # low byte 4: longer than most of the slices
+    (39996, 2),         # 5000 bytes: lands in the macroblock data of some
+    (0xfffffffc, 2),    # 4 + minus4 wraps to 0: no bits at all
+    (0xfffffffd, 0xfffffffc),
+])
+def test_hostile_sps_field_widths(engine, fn4, poc4):
+    """The reference checks neither log2_max_frame_num_minus4 nor
+    log2_max_pic_order_cnt_lsb_minus4 (src/h264_syntax.h:309-313): its reader
+    takes any u(n) (all n bits consumed, last 32 kept), its writer up to 64 bits.
+    Read and write kernels must do the same, not truncate the width."""
+    cfg = streams.small_cfg(log2_max_frame_num_minus4=fn4,
+                            log2_max_poc_lsb_minus4=poc4)
+    slices = [streams.rich_slice(cfg, 40 + seed, st, frame_num=0x9abcdef1,
+                                 poc_lsb=0xfedcba98, pm_pcm=pcm)
+              for seed in range(4) for st in (2, 0, 1) for pcm in (0, 900)]
+    nals = [gen.slice_nal(cfg, s) for s in slices]
+    ref = orc.parse_nalus([gen.sps(cfg), gen.pps(cfg)] + nals, flags=1)
+    # separately: a failed write-back zeroes the context's header length
+    # (ref src/h264_syntax.h:1250), which the result record would then show
+    ref_w = orc.parse_nalus([gen.sps(cfg), gen.pps(cfg)] + nals, flags=1,
+                            want=orc.ORC_REC_WANT_REWRITE)
+    assert ref.statuses[0] == 0 and ref.statuses[1] == 0
+    assert ref.sps[0].log2_max_frame_num_minus4 == fn4
+    if 4 + fn4 <= 40000 or 4 + fn4 >= 1 << 32:
+        assert ref.headers[0].frame_num == (0x9abcdef1 & ((1 << min(
+            32, (fn4 + 4) & 0xffffffff)) - 1))
+    params = make_params(ref)
+    buf, offs, sizes = streams.pack_nals(nals)
+    d_buf = engine.upload(buf)
+    descs = [(o, s, params.epoch) for o, s in zip(offs, sizes)]
+    out = engine.decode_slices(params, d_buf, descs, reader_flags=1,
+                               tier=TIER_T2, mb_capacity=64, want_headers=True)
+    res = engine.fetch_results(out)
+    hdrs = engine.fetch_headers(out)
+    good = 0  # the oracle keeps a header per slice whose callback fired
+    for i in range(len(slices)):
+        assert res[i].status == ref.statuses[i + 2], i
+        assert result_fields(res[i]) == result_fields(ref.results[i]), i
+        if res[i].status == 0:
+            assert bytes(hdrs[i]) == bytes(ref.headers[good]), i
+            good += 1
+            mb = engine.fetch_mb(out, i, res[i].mb_count)
+            st = t2_stride(res[i].chroma_array_type)
+            assert np.array_equal(mb[:, :st], ref.mb_records(i)), i
+    if all((4 + x) & 0xffffffff <= 40000 for x in (fn4, poc4)):
+        assert good == len(slices)
+    else:
+        assert good < len(slices)
+    # write-back: same bytes, or the same refusal
+    d_out, ooffs, osizes = engine.write_slices(params, d_buf, out,
+                                               max(sizes) + 64)
+    raw = engine.download(d_out)
+    rew = {w.nal_index: w for w in ref_w.rewrite_idx}
+    for i in range(len(slices)):
+        if res[i].status != 0:
+            continue
+        w = rew[i + 2]
+        if w.res < 0:
+            assert osizes[i] == w.res, (i, osizes[i], w.res)
+            continue
+        assert osizes[i] == w.len, (i, osizes[i], w.len)
+        got = raw[int(ooffs[i]):int(ooffs[i]) + w.len].tobytes()
+        assert got == ref_w.rewrites[w.off:w.off + w.len], i

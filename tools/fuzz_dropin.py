@@ -1,0 +1,67 @@
+#!/usr/bin/env python3
+"""Hostile input through the DROP-IN API: mixed NAL units (parameter sets, SEI,
+AUD, filler, slices of all types), most of them damaged, NAL by NAL through
+h264_reader_parse_nalu and as an Annex-B stream through h264_reader_parse;
+status codes and the complete callback log must equal the oracle's.
+
+    python tools/fuzz_dropin.py [first_seed] [count]
+"""
+import os
+import random
+import sys
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+sys.path.insert(0, os.path.join(ROOT, "tests"))
+
+import orc  # noqa: E402
+import prod  # noqa: E402
+import streams  # noqa: E402
+from test_gpu_fuzz import mutate  # noqa: E402
+
+
+def one(seed):
+    rnd = random.Random(seed)
+    cf, bd = rnd.choice([(1, 0), (1, 0), (0, 0), (2, 2), (3, 0)])
+    cfg = streams.small_cfg(cf=cf, bd=bd)
+    nals = streams.mixed_nals(cfg, n_slices=20, seed0=seed * 31)
+    out = []
+    for i, n in enumerate(nals):
+        out.append(mutate(n, rnd) if (i >= 2 and rnd.random() < 0.6) else n)
+    flags = rnd.choice([0, 1, 1])
+    ref = orc.parse_nalus(out, flags=flags, want=0)
+    got = prod.parse_nalus(out, flags=flags)
+    if got.statuses != ref.statuses:
+        k = next(i for i, (a, b) in enumerate(zip(got.statuses, ref.statuses))
+                 if a != b)
+        return "seed %d nal %d status %d != %d (%s)" % (
+            seed, k, got.statuses[k], ref.statuses[k], out[k][:24].hex())
+    if got.event_tuples() != ref.event_tuples():
+        return "seed %d: callback logs differ (per NAL)" % seed
+    if bytes(got.headers) != bytes(ref.headers):
+        return "seed %d: slice headers differ" % seed
+    data = streams.annexb(out, long_codes=[rnd.random() < 0.5 for _ in out])
+    ref = orc.parse_stream(data, flags=flags, want=0)
+    got = prod.parse_stream(data, flags=flags)
+    want = [e for e in ref.event_tuples() if e[0] != 13]
+    if got.consumed != ref.consumed or got.event_tuples() != want:
+        return "seed %d: stream parse differs" % seed
+    return None
+
+
+def main():
+    import resource
+    resource.setrlimit(resource.RLIMIT_AS, (96 << 30, 96 << 30))
+    first = int(sys.argv[1]) if len(sys.argv) > 1 else 1
+    count = int(sys.argv[2]) if len(sys.argv) > 2 else 50
+    bad = 0
+    for seed in range(first, first + count):
+        msg = one(seed)
+        if msg:
+            print(msg, flush=True)
+            bad += 1
+    print("seeds %d..%d divergences: %d" % (first, first + count - 1, bad))
+
+
+if __name__ == "__main__":
+    main()
