@@ -338,8 +338,9 @@ H264_API int h264_amd_cabac_init_states(struct h264_amd_engine *eng,
 					uint8_t *d_states);
 
 /* Kernel timing: duration in ms of the most recent launch of the named
- * kernel family ("scan", "decode", "write", "synth"), measured with HIP
- * events on the engine stream.  Synchronises. */
+ * kernel family ("scan" = the marking kernel that reads the stream,
+ * "scan_all" = marking + prefix + placement, "decode", "write", "synth"),
+ * measured with HIP events on the engine stream.  Synchronises. */
 H264_API int h264_amd_last_kernel_ms(struct h264_amd_engine *eng,
 				     const char *family,
 				     float *ms);

@@ -60,7 +60,7 @@ static int hip_err(hipError_t e)
 		}                                                              \
 	} while (0)
 
-enum { FAM_SCAN, FAM_DECODE, FAM_WRITE, FAM_SYNTH, FAM_COUNT };
+enum { FAM_SCAN, FAM_DECODE, FAM_WRITE, FAM_SYNTH, FAM_SCAN_ALL, FAM_COUNT };
 
 /* Serial numbers are process-wide so that a params object allocated at the
  * address of a freed one can never look "unchanged" to an engine's cache. */
@@ -97,6 +97,7 @@ struct h264_amd_engine {
 	bool timed[FAM_COUNT];
 	/* scan scratch */
 	scan_scratch scan;
+	uint32_t scan_seg_override; /* H264_AMD_SCAN_SEG (experiments, tests) */
 };
 
 /* ---- lane tables from the standard's bit strings -------------------------- */
@@ -216,6 +217,13 @@ extern "C" int h264_amd_engine_new(int device, void *hip_stream,
 		for (int k = 0; k < 2; k++)
 			HIP_TRY(hipEventCreate(&e->ev[f][k]));
 	{
+		const char *v = getenv("H264_AMD_SCAN_SEG");
+		unsigned long seg = v ? strtoul(v, NULL, 0) : 0;
+		if (seg >= SCAN_BLOCK_BYTES && seg <= (1u << 30) &&
+		    seg % SCAN_BLOCK_BYTES == 0)
+			e->scan_seg_override = (uint32_t)seg;
+	}
+	{
 		dev_vlc_tables *h = new dev_vlc_tables;
 		vlc_build_tables(h);
 		HIP_TRY(hipMalloc((void **)&e->d_vlc, sizeof(*h)));
@@ -319,7 +327,7 @@ extern "C" int h264_amd_last_kernel_ms(struct h264_amd_engine *e,
 				       const char *family, float *ms)
 {
 	static const char *const names[FAM_COUNT] = {"scan", "decode", "write",
-						     "synth"};
+						     "synth", "scan_all"};
 	if (e == NULL || family == NULL || ms == NULL)
 		return -EINVAL;
 	for (int f = 0; f < FAM_COUNT; f++) {

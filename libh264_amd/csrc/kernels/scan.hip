@@ -15,16 +15,20 @@
  * the reference does.
  *
  * Kernel structure (HBM bound; every input byte is read once):
- *   k_scan_mark   each WAVE walks one 16 KiB segment in 1 KiB steps (64 lanes
- *                 x 16 B, four steps in flight), builds E/S bit masks with
- *                 byte-parallel arithmetic, and -- because at most one NAL is
- *                 open at any time -- resolves starts and ends with a scalar
- *                 state machine that only runs on the (rare) steps containing
- *                 a pattern.  NAL records go to a per-launch list, a NAL still
- *                 open at the end of the segment is left unresolved.
- *   k_scan_place  exclusive scan of the per-segment counts, resolves open NALs
- *                 with the first E of the following segments and scatters the
- *                 records to their final, stream-ordered position.
+ *   k_scan_mark   each WAVE walks one segment (16 KiB or more) in 1 KiB steps
+ *                 (64 lanes x 16 B, one 4 KiB block in flight ahead), asks
+ *                 whether the step holds a pair of zero bytes at all and only
+ *                 then builds the E/S bit masks and -- because at most one NAL
+ *                 is open at any time -- resolves starts and ends with a scalar
+ *                 state machine.  A segment has one record slot of its own per
+ *                 SCAN_INLINE_BYTES: NAL units up to that count use them (no
+ *                 atomics: a single list counter serialises at ~9 ns per NAL
+ *                 unit, measured), further ones go to an overflow list.  A NAL
+ *                 still open at the end of the segment is left unresolved.
+ *   k_scan_prefix exclusive scan of the per-segment counts.
+ *   k_scan_place  resolves open NALs with the first E of the following
+ *                 segments and scatters the records to their final,
+ *                 stream-ordered position; reports the last NAL's end.
  */
 #ifndef H264_AMD_SCAN_HIP
 #define H264_AMD_SCAN_HIP
@@ -34,23 +38,36 @@
 
 #include <h264_amd.h>
 
-#define SCAN_SEG_BYTES 16384u /* per wave */
+#define SCAN_BLOCK_BYTES 4096u /* four 1 KiB steps in flight per wave */
+#define SCAN_SEG_MIN 16384u /* bytes per wave: small buffers */
+#define SCAN_SEG_MAX 262144u
+#define SCAN_TARGET_WAVES 8192u /* 256 CUs x 32 waves */
 #define SCAN_WAVES_PER_BLOCK 4u
 #define SCAN_NONE 0xffffffffffffffffull
+
+#define SCAN_INLINE_BYTES 2048u /* one atomic-free record slot per this many bytes */
 
 struct scan_rec {
 	uint64_t start, end; /* end == SCAN_NONE: open at the end of the segment */
 	uint32_t seg, local; /* segment and ordinal inside it */
 };
 
+struct scan_inline_rec {
+	uint64_t start, end;
+};
+
 struct scan_scratch {
-	scan_rec *d_recs;
+	scan_rec *d_recs; /* overflow list */
 	size_t cap_recs;
+	scan_inline_rec *d_inline; /* [segment][seg_bytes / SCAN_INLINE_BYTES] */
+	size_t cap_inline;
 	uint32_t *d_seg_count; /* NALs opened per segment */
 	uint64_t *d_seg_first_e; /* first E position per segment or SCAN_NONE */
 	uint32_t *d_seg_base;
 	size_t cap_segs;
-	uint32_t *d_counter; /* [0] records appended, [1] total NALs */
+	/* [0] overflow records appended, [1] total NALs, [2..3] end of the last
+	 * NAL placed (uint64) */
+	uint32_t *d_counter;
 };
 
 /* 0x80 in every byte of x that is zero (exact, no cross-byte carries) */
@@ -91,12 +108,127 @@ struct scan_mark_args {
 	const uint8_t *buf;
 	uint64_t len;
 	uint32_t nsegs;
+	uint32_t seg_bytes; /* multiple of SCAN_BLOCK_BYTES */
 	scan_rec *recs;
 	uint32_t cap_recs;
+	scan_inline_rec *inl;
+	uint32_t inline_per_seg;
 	uint32_t *seg_count;
 	uint64_t *seg_first_e;
 	uint32_t *counter;
 };
+
+/* wave-uniform walk state of one segment */
+struct scan_state {
+	uint32_t carry; /* bits 0-7: byte before the previous one, 8-15: previous */
+	uint32_t opened; /* NALs opened in this segment */
+	uint64_t pending; /* payload start of the open NAL */
+	uint64_t first_e;
+};
+
+/* value of the lane below (lane 0: `first`): one DPP move, no LDS crossbar */
+__device__ __forceinline__ uint32_t scan_from_lane_below(uint32_t v, uint32_t first,
+							 uint32_t lane)
+{
+	uint32_t up = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x138 /* wave_shr:1 */,
+							    0xf, 0xf, true);
+	return lane == 0 ? first : up;
+}
+
+/* NAL number `local` of segment `seg` is complete (or, end == SCAN_NONE, still
+ * open where the segment ends) */
+__device__ __forceinline__ void scan_emit(const scan_mark_args &a, uint32_t seg,
+					  uint32_t local, uint64_t start,
+					  uint64_t end, uint32_t lane)
+{
+	if (lane != 0)
+		return;
+	if (local < a.inline_per_seg) {
+		scan_inline_rec r;
+		r.start = start;
+		r.end = end;
+		a.inl[(size_t)seg * a.inline_per_seg + local] = r;
+		return;
+	}
+	uint32_t slot = atomicAdd(&a.counter[0], 1u);
+	if (slot < a.cap_recs) {
+		scan_rec r;
+		r.start = start;
+		r.end = end;
+		r.seg = seg;
+		r.local = local;
+		a.recs[slot] = r;
+	}
+}
+
+/* One 1 KiB step: lane l holds bytes cbase + 16 l .. + 15 in q.
+ *
+ * Entropy-coded data holds no two consecutive zero bytes except at NAL
+ * boundaries (that is what emulation prevention is for), and every code needs
+ * such a pair.  The step therefore first asks, in the 0x80-flag-per-byte
+ * domain, whether ANY lane sees a zero pair (or the step inherits one): about
+ * 30 vector instructions per 16 bytes.  Only then are the exact E / S masks
+ * built and walked by the scalar state machine. */
+__device__ __forceinline__ void scan_step(const scan_mark_args &a, scan_state &st,
+					  uint4 q, uint64_t cbase, uint32_t seg,
+					  uint32_t lane)
+{
+	const uint32_t w[4] = {q.x, q.y, q.z, q.w};
+	uint32_t z[4];
+#pragma unroll
+	for (int k = 0; k < 4; k++)
+		z[k] = scan_zero_bytes(w[k]);
+	/* zero flags of the four bytes before this lane's 16 (bits 23, 31 used) */
+	const uint32_t zc = ((st.carry & 0xffu) == 0 ? 0x00800000u : 0u) |
+			    ((st.carry >> 8) == 0 ? 0x80000000u : 0u);
+	const uint32_t zb = scan_from_lane_below(z[3], zc, lane);
+	/* flag at byte j: bytes j - 1 and j are both zero */
+	uint32_t pair = z[0] & __builtin_amdgcn_alignbit(z[0], zb, 24);
+	pair |= z[1] & __builtin_amdgcn_alignbit(z[1], z[0], 24);
+	pair |= z[2] & __builtin_amdgcn_alignbit(z[2], z[1], 24);
+	pair |= z[3] & __builtin_amdgcn_alignbit(z[3], z[2], 24);
+	const uint32_t carry_in = st.carry;
+	/* next step's carry: last two bytes of lane 63 */
+	st.carry = (uint32_t)__builtin_amdgcn_readlane((int)(w[3] >> 16), 63);
+	if (__ballot(pair != 0) == 0 && carry_in != 0)
+		return;
+
+	uint32_t z16 = 0, le16 = 0;
+#pragma unroll
+	for (int k = 0; k < 4; k++) {
+		z16 |= scan_movemask(z[k]) << (4 * k);
+		le16 |= scan_movemask(scan_zero_bytes(w[k] & 0xfefefefeu)) << (4 * k);
+	}
+	uint32_t zprev = ((zb >> 23) & 1u) | ((zb >> 30) & 2u);
+	uint32_t z18 = (z16 << 2) | zprev; /* bit j+2 = byte j */
+	/* code ENDING at byte j: bytes j-2, j-1 zero, byte j <= 1 */
+	uint32_t e16 = z18 & (z18 >> 1) & le16;
+	uint32_t s16 = e16 & ~z16;
+
+	unsigned long long em = __ballot(e16 != 0);
+	while (em) {
+		int l = __builtin_ctzll(em);
+		em &= em - 1;
+		uint32_t e = (uint32_t)__builtin_amdgcn_readlane((int)e16, l);
+		uint32_t s = (uint32_t)__builtin_amdgcn_readlane((int)s16, l);
+		while (e) {
+			uint32_t j = (uint32_t)__builtin_ctz(e);
+			e &= e - 1;
+			/* position of the code's first byte */
+			uint64_t p = cbase + 16u * (uint32_t)l + j - 2u;
+			if (st.first_e == SCAN_NONE)
+				st.first_e = p;
+			if (st.pending != SCAN_NONE) {
+				scan_emit(a, seg, st.opened - 1u, st.pending, p, lane);
+				st.pending = SCAN_NONE;
+			}
+			if ((s >> j) & 1u) {
+				st.pending = p + 3u;
+				st.opened++;
+			}
+		}
+	}
+}
 
 extern "C" __global__ void __launch_bounds__(64 * SCAN_WAVES_PER_BLOCK)
 h264_amd_k_scan_mark(scan_mark_args a)
@@ -106,168 +238,179 @@ h264_amd_k_scan_mark(scan_mark_args a)
 		(int)(blockIdx.x * SCAN_WAVES_PER_BLOCK + (threadIdx.x >> 6)));
 	if (seg >= a.nsegs)
 		return;
-	const uint64_t lo = (uint64_t)seg * SCAN_SEG_BYTES;
-	uint64_t hi = lo + SCAN_SEG_BYTES;
+	const uint64_t lo = (uint64_t)seg * a.seg_bytes;
+	uint64_t hi = lo + a.seg_bytes;
 	if (hi > a.len)
 		hi = a.len;
+	/* blocks of 4 KiB that lie wholly inside the buffer take plain 16-byte
+	 * loads, software-pipelined one block ahead; only the buffer's last,
+	 * ragged block goes through the careful loader */
+	const uint64_t full_hi = lo + ((hi - lo) & ~(uint64_t)(SCAN_BLOCK_BYTES - 1u));
 
-	/* the two bytes before the segment (0xff before the buffer) */
-	uint32_t carry = 0xffffu; /* bits 0-7: byte lo-2, 8-15: byte lo-1 */
-	if (lo >= 2)
-		carry = (uint32_t)a.buf[lo - 2] | ((uint32_t)a.buf[lo - 1] << 8);
-	carry = (uint32_t)__builtin_amdgcn_readfirstlane((int)carry);
-
-	uint64_t pending = SCAN_NONE; /* payload start of the open NAL */
-	uint64_t first_e = SCAN_NONE;
-	uint32_t opened = 0; /* NALs opened in this segment */
-
-	for (uint64_t pos = lo; pos < hi; pos += 4096u) {
-		uint4 q[4];
+	uint4 q[4], nq[4];
+	if (lo < full_hi) {
 #pragma unroll
-		for (int u = 0; u < 4; u++) {
-			uint64_t off = pos + 1024u * u + 16u * lane;
-			q[u] = off < hi ? scan_load16(a.buf, off, a.len)
-					: make_uint4(~0u, ~0u, ~0u, ~0u);
-		}
-#pragma unroll
-		for (int u = 0; u < 4; u++) {
-			const uint64_t cbase = pos + 1024u * u;
-			if (cbase >= hi)
-				break;
-			const uint32_t w[4] = {q[u].x, q[u].y, q[u].z, q[u].w};
-			uint32_t z16 = 0, le16 = 0;
-#pragma unroll
-			for (int k = 0; k < 4; k++) {
-				z16 |= scan_movemask(scan_zero_bytes(w[k])) << (4 * k);
-				le16 |= scan_movemask(scan_zero_bytes(w[k] & 0xfefefefeu))
-					<< (4 * k);
-			}
-			/* zero flags of the two bytes before this lane's 16 */
-			uint32_t zup = (uint32_t)__shfl_up((int)z16, 1) >> 14;
-			uint32_t zc = ((carry & 0xffu) == 0 ? 1u : 0u) |
-				      ((carry >> 8) == 0 ? 2u : 0u);
-			uint32_t zprev = lane == 0 ? zc : zup;
-			uint32_t z18 = (z16 << 2) | zprev; /* bit j+2 = byte j */
-			/* code ENDING at byte j: bytes j-2, j-1 zero, byte j <= 1 */
-			uint32_t e16 = z18 & (z18 >> 1) & le16;
-			uint32_t s16 = e16 & ~z16;
-			/* next step's carry: last two bytes of lane 63 */
-			carry = (uint32_t)__builtin_amdgcn_readlane((int)(w[3] >> 16), 63);
-
-			unsigned long long em = __ballot(e16 != 0);
-			while (em) {
-				int l = __builtin_ctzll(em);
-				em &= em - 1;
-				uint32_t e = (uint32_t)__builtin_amdgcn_readlane((int)e16, l);
-				uint32_t s = (uint32_t)__builtin_amdgcn_readlane((int)s16, l);
-				while (e) {
-					uint32_t j = (uint32_t)__builtin_ctz(e);
-					e &= e - 1;
-					/* position of the code's first byte */
-					uint64_t p = cbase + 16u * (uint32_t)l + j - 2u;
-					if (first_e == SCAN_NONE)
-						first_e = p;
-					if (pending != SCAN_NONE) {
-						if (lane == 0) {
-							uint32_t slot = atomicAdd(&a.counter[0], 1u);
-							if (slot < a.cap_recs) {
-								scan_rec r;
-								r.start = pending;
-								r.end = p;
-								r.seg = seg;
-								r.local = opened - 1u;
-								a.recs[slot] = r;
-							}
-						}
-						pending = SCAN_NONE;
-					}
-					if ((s >> j) & 1u) {
-						pending = p + 3u;
-						opened++;
-					}
-				}
-			}
-		}
+		for (int u = 0; u < 4; u++)
+			q[u] = *reinterpret_cast<const uint4 *>(a.buf + lo + 1024u * u +
+								16u * lane);
 	}
-	if (lane == 0) {
-		if (pending != SCAN_NONE) {
-			uint32_t slot = atomicAdd(&a.counter[0], 1u);
-			if (slot < a.cap_recs) {
-				scan_rec r;
-				r.start = pending;
-				r.end = SCAN_NONE;
-				r.seg = seg;
-				r.local = opened - 1u;
-				a.recs[slot] = r;
-			}
+	scan_state st;
+	/* the two bytes before the segment (0xff before the buffer) */
+	st.carry = 0xffffu;
+	if (lo >= 2)
+		st.carry = (uint32_t)a.buf[lo - 2] | ((uint32_t)a.buf[lo - 1] << 8);
+	st.carry = (uint32_t)__builtin_amdgcn_readfirstlane((int)st.carry);
+	st.pending = SCAN_NONE;
+	st.first_e = SCAN_NONE;
+	st.opened = 0;
+
+	for (uint64_t pos = lo; pos < full_hi; pos += SCAN_BLOCK_BYTES) {
+		const uint64_t nx = pos + SCAN_BLOCK_BYTES;
+		if (nx < full_hi) {
+#pragma unroll
+			for (int u = 0; u < 4; u++)
+				nq[u] = *reinterpret_cast<const uint4 *>(
+					a.buf + nx + 1024u * u + 16u * lane);
 		}
-		a.seg_count[seg] = opened;
-		a.seg_first_e[seg] = first_e;
+#pragma unroll
+		for (int u = 0; u < 4; u++)
+			scan_step(a, st, q[u], pos + 1024u * u, seg, lane);
+#pragma unroll
+		for (int u = 0; u < 4; u++)
+			q[u] = nq[u];
+	}
+	for (uint64_t cbase = full_hi; cbase < hi; cbase += 1024u) {
+		uint64_t off = cbase + 16u * lane;
+		uint4 t = off < hi ? scan_load16(a.buf, off, a.len)
+				   : make_uint4(~0u, ~0u, ~0u, ~0u);
+		scan_step(a, st, t, cbase, seg, lane);
+	}
+	if (st.pending != SCAN_NONE)
+		scan_emit(a, seg, st.opened - 1u, st.pending, SCAN_NONE, lane);
+	if (lane == 0) {
+		a.seg_count[seg] = st.opened;
+		a.seg_first_e[seg] = st.first_e;
 	}
 }
 
 /* Single block: exclusive scan of seg_count into seg_base, total into
- * counter[1]. */
+ * counter[1].  Tiles of 4096 counts, 16 B per thread, coalesced; inside a tile
+ * a shuffle scan per wave and one LDS exchange of the 16 wave totals. */
 extern "C" __global__ void __launch_bounds__(1024)
 h264_amd_k_scan_prefix(const uint32_t *seg_count, uint32_t *seg_base,
 		       uint32_t nsegs, uint32_t *counter)
 {
-	__shared__ uint32_t part[1024];
-	const uint32_t t = threadIdx.x;
-	const uint32_t per = (nsegs + 1023u) / 1024u;
-	uint32_t b = t * per, sum = 0;
-	for (uint32_t i = b; i < b + per && i < nsegs; i++)
-		sum += seg_count[i];
-	part[t] = sum;
-	__syncthreads();
-	for (uint32_t d = 1; d < 1024; d <<= 1) {
-		uint32_t v = t >= d ? part[t - d] : 0;
+	__shared__ uint32_t wave_tot[16];
+	const uint32_t t = threadIdx.x, lane = t & 63u, wv = t >> 6;
+	uint32_t running = 0;
+	for (uint32_t tile = 0; tile < nsegs; tile += 4096u) {
+		const uint32_t i = tile + 4u * t;
+		uint32_t c[4];
+#pragma unroll
+		for (int k = 0; k < 4; k++)
+			c[k] = i + k < nsegs ? seg_count[i + k] : 0u;
+		const uint32_t own = c[0] + c[1] + c[2] + c[3];
+		uint32_t incl = own;
+#pragma unroll
+		for (int d = 1; d < 64; d <<= 1) {
+			uint32_t v = (uint32_t)__shfl_up((int)incl, d);
+			if (lane >= (uint32_t)d)
+				incl += v;
+		}
+		if (lane == 63)
+			wave_tot[wv] = incl;
 		__syncthreads();
-		part[t] += v;
+		uint32_t before = running;
+		for (uint32_t w = 0; w < 16; w++) {
+			uint32_t x = wave_tot[w];
+			if (w < wv)
+				before += x;
+			running += x;
+		}
 		__syncthreads();
+		uint32_t run = before + incl - own;
+#pragma unroll
+		for (int k = 0; k < 4; k++) {
+			if (i + k < nsegs)
+				seg_base[i + k] = run;
+			run += c[k];
+		}
 	}
-	uint32_t run = part[t] - sum;
-	for (uint32_t i = b; i < b + per && i < nsegs; i++) {
-		seg_base[i] = run;
-		run += seg_count[i];
+	if (t == 0) {
+		counter[1] = running;
+		counter[2] = 0;
+		counter[3] = 0;
 	}
-	if (t == 1023)
-		counter[1] = part[1023];
 }
 
-/* One thread per record: resolve an open end with the first E of a following
- * segment and scatter to the stream-ordered slot. */
-extern "C" __global__ void __launch_bounds__(256)
-h264_amd_k_scan_place(const scan_rec *recs, uint32_t nrecs,
-		      const uint32_t *seg_base, const uint64_t *seg_first_e,
-		      uint32_t nsegs, uint64_t len, struct h264_amd_nal *out,
-		      uint32_t cap)
+struct scan_place_args {
+	const scan_inline_rec *inl;
+	uint32_t inline_per_seg;
+	const scan_rec *recs; /* overflow list */
+	uint32_t cap_recs;
+	const uint32_t *seg_count;
+	const uint32_t *seg_base;
+	const uint64_t *seg_first_e;
+	uint32_t nsegs;
+	uint64_t len;
+	struct h264_amd_nal *out;
+	uint32_t cap;
+	uint32_t *counter;
+};
+
+__device__ __forceinline__ void scan_place_one(const scan_place_args &a, uint32_t seg,
+					       uint32_t local, uint64_t start,
+					       uint64_t end)
 {
-	uint32_t i = blockIdx.x * 256u + threadIdx.x;
-	if (i >= nrecs)
-		return;
-	scan_rec r = recs[i];
-	uint64_t end = r.end;
 	if (end == SCAN_NONE) {
-		end = len;
-		for (uint32_t s = r.seg + 1; s < nsegs; s++) {
-			uint64_t f = seg_first_e[s];
+		end = a.len;
+		for (uint32_t s = seg + 1; s < a.nsegs; s++) {
+			uint64_t f = a.seg_first_e[s];
 			if (f != SCAN_NONE) {
 				end = f;
 				break;
 			}
 		}
 	}
-	uint32_t idx = seg_base[r.seg] + r.local;
-	if (idx < cap) {
-		out[idx].start = r.start;
-		out[idx].end = end;
+	uint32_t idx = a.seg_base[seg] + local;
+	if (idx < a.cap) {
+		a.out[idx].start = start;
+		a.out[idx].end = end;
+	}
+	/* the stream's last NAL: its end is what h264_reader_parse consumed */
+	if (idx + 1u == a.counter[1])
+		*reinterpret_cast<uint64_t *>(a.counter + 2) = end;
+}
+
+/* One thread per inline slot, then the same threads stride over the overflow
+ * list (its length is read on the device: no host round trip in between). */
+extern "C" __global__ void __launch_bounds__(256)
+h264_amd_k_scan_place(scan_place_args a)
+{
+	const uint64_t gid = (uint64_t)blockIdx.x * 256u + threadIdx.x;
+	const uint64_t n_inline = (uint64_t)a.nsegs * a.inline_per_seg;
+	if (gid < n_inline) {
+		uint32_t seg = (uint32_t)(gid / a.inline_per_seg);
+		uint32_t local = (uint32_t)(gid % a.inline_per_seg);
+		if (local < a.seg_count[seg]) {
+			scan_inline_rec r = a.inl[gid];
+			scan_place_one(a, seg, local, r.start, r.end);
+		}
+	}
+	uint32_t nrecs = a.counter[0];
+	if (nrecs > a.cap_recs)
+		nrecs = a.cap_recs;
+	const uint64_t stride = (uint64_t)gridDim.x * 256u;
+	for (uint64_t i = gid; i < nrecs; i += stride) {
+		scan_rec r = a.recs[i];
+		scan_place_one(a, r.seg, r.local, r.start, r.end);
 	}
 }
 
 static inline void scan_scratch_free(scan_scratch *s)
 {
 	hipFree(s->d_recs);
+	hipFree(s->d_inline);
 	hipFree(s->d_seg_count);
 	hipFree(s->d_seg_first_e);
 	hipFree(s->d_seg_base);

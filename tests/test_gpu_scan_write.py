@@ -76,6 +76,33 @@ def test_scan_segment_boundaries(engine):
             check_scan(engine, bytes(data))
 
 
+@pytest.mark.parametrize("seg", [4096, 65536])
+def test_scan_other_segment_sizes(seg, monkeypatch):
+    """Large buffers are walked in longer per-wave segments (engine picks the
+    size from the buffer length); H264_AMD_SCAN_SEG forces one so that small
+    inputs reach the same code: many tiny segments, and segments holding
+    several pipelined 4 KiB blocks."""
+    import libh264_amd
+    monkeypatch.setenv("H264_AMD_SCAN_SEG", str(seg))
+    eng = libh264_amd.Engine(0)
+    rnd = random.Random(seg)
+    # sparse codes in zero-free payload (the fast filter's normal diet) ...
+    data = bytearray(rnd.randrange(1, 256) for _ in range(300000))
+    for p in sorted(rnd.sample(range(0, len(data) - 8), 60)):
+        data[p:p + 4] = rnd.choice([b"\x00\x00\x01\x65", b"\x00\x00\x00\x01",
+                                    b"\x00\x00\x00\x00", b"\x00\x00\x03\x00"])
+    # ... codes straddling every kind of edge ...
+    for edge in (1024, 4096, 8192, seg, 2 * seg, 3 * seg + 1024):
+        for shift in (-3, -2, -1, 0, 1):
+            p = edge + shift + 16 * (shift + 3)
+            if p + 4 < len(data):
+                data[p:p + 3] = b"\x00\x00\x01"
+    check_scan(eng, bytes(data))
+    # ... and byte soup
+    soup = bytes(rnd.choice([0, 0, 0, 1, 3, 7, 255]) for _ in range(70001))
+    check_scan(eng, soup)
+
+
 def test_scan_mixed_stream(engine):
     cfg = streams.small_cfg()
     nals = [gen.sps(cfg), gen.pps(cfg), gen.aud(0), gen.sei_user_data(300, 3)]
