@@ -125,7 +125,7 @@ static inline uint32_t h264_amd_t2_stride(uint32_t chroma_array_type)
 #define H264_AMD_SR_CABAC 0x0004 /* CABAC slice: data kept raw */
 
 /* Engine-specific status values besides negative errno */
-#define H264_AMD_E_UNSUPPORTED (-ENOSYS) /* MBAFF / FMO: out of scope */
+#define H264_AMD_E_UNSUPPORTED (-ENOSYS) /* MBAFF / FMO; CABAC beyond the subset */
 #define H264_AMD_E_MB_OVERFLOW (-EOVERFLOW) /* more MBs than mb_capacity */
 /* Most macroblocks one slice may deliver (64 pictures of 4096 x 2304): where the
  * drop-in reader stops growing a slice's record area, and where the oracle
@@ -256,6 +256,16 @@ H264_API int h264_amd_scan(struct h264_amd_engine *eng,
 			   size_t *consumed);
 
 /* ---- slice decode -------------------------------------------------------- */
+/* reader_flags bit beside H264_READER_FLAGS_SLICE_DATA: also walk the slice
+ * data of CABAC slices as far as the CABAC SUBSET goes.  The reference has no
+ * CABAC decoder (it returns before CABAC slice data,
+ * src/h264_syntax_slice_data.h:715-717), so this is an extension and off by
+ * default; the drop-in library never sets it.  The subset is what the
+ * reference's own writers emit: mb_skip_flag = 1 macroblocks in P/SP/B slices,
+ * I_16x16 macroblocks without residual in I slices, end_of_slice_flag.  A
+ * slice leaving the subset ends with H264_AMD_E_UNSUPPORTED after the
+ * macroblocks decoded so far.  Needs d_headers. */
+#define H264_AMD_READER_FLAGS_CABAC_SUBSET 0x100u
 struct h264_amd_decode_args {
 	const uint8_t *d_buf; /* NAL bytes */
 	const struct h264_amd_slice_desc *d_descs; /* [n] */

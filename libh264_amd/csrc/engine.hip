@@ -27,6 +27,7 @@
 #include "kernels/scan.hip"
 #include "kernels/slice_decode.hip"
 #include "kernels/slice_write.hip"
+#include "kernels/cabac_decode.hip"
 
 /* ---- helpers --------------------------------------------------------------- */
 
@@ -60,7 +61,7 @@ static int hip_err(hipError_t e)
 		}                                                              \
 	} while (0)
 
-enum { FAM_SCAN, FAM_DECODE, FAM_WRITE, FAM_SYNTH, FAM_SCAN_ALL, FAM_COUNT };
+enum { FAM_SCAN, FAM_DECODE, FAM_WRITE, FAM_SYNTH, FAM_SCAN_ALL, FAM_CABAC, FAM_COUNT };
 
 /* Serial numbers are process-wide so that a params object allocated at the
  * address of a freed one can never look "unchanged" to an engine's cache. */
@@ -327,7 +328,7 @@ extern "C" int h264_amd_last_kernel_ms(struct h264_amd_engine *e,
 				       const char *family, float *ms)
 {
 	static const char *const names[FAM_COUNT] = {"scan", "decode", "write",
-						     "synth", "scan_all"};
+						     "synth", "scan_all", "cabac"};
 	if (e == NULL || family == NULL || ms == NULL)
 		return -EINVAL;
 	for (int f = 0; f < FAM_COUNT; f++) {
@@ -524,6 +525,9 @@ extern "C" int h264_amd_decode_slices(struct h264_amd_engine *e,
 	if (((uintptr_t)args->d_descs & 7u) || ((uintptr_t)args->d_results & 15u) ||
 	    ((uintptr_t)args->d_headers & 15u))
 		return -EINVAL;
+	if ((args->reader_flags & H264_AMD_READER_FLAGS_CABAC_SUBSET) &&
+	    args->d_headers == NULL)
+		return -EINVAL; /* the CABAC pass reads the header images */
 	uint32_t stride = args->mb_stride;
 	if (args->d_mb_out != NULL) {
 		if ((uintptr_t)args->d_mb_out & 15u)
@@ -586,6 +590,43 @@ extern "C" int h264_amd_decode_slices(struct h264_amd_engine *e,
 	HIP_TRY(hipGetLastError());
 	HIP_TRY(hipEventRecord(e->ev[FAM_DECODE][1], e->stream));
 	e->timed[FAM_DECODE] = true;
+
+	if ((args->reader_flags & H264_AMD_READER_FLAGS_CABAC_SUBSET) &&
+	    (args->reader_flags & H264_READER_FLAGS_SLICE_DATA)) {
+		/* second pass over the slices the first one flagged as CABAC */
+		cb_args c;
+		memset(&c, 0, sizeof(c));
+		c.buf = a.buf;
+		c.descs = a.descs;
+		c.n = a.n;
+		c.spsv = a.spsv;
+		c.ppsv = a.ppsv;
+		c.epochs = a.epochs;
+		c.n_sps = a.n_sps;
+		c.n_pps = a.n_pps;
+		c.n_epochs = a.n_epochs;
+		c.tab = e->d_cabac;
+		c.tier = a.tier;
+		c.mb_capacity = a.mb_capacity;
+		c.mb_stride = a.mb_stride;
+		c.results = a.results;
+		c.headers = a.headers;
+		c.mb_out = a.mb_out;
+		c.row_pitch = a.row_pitch;
+		size_t clds = CB_ROW_OFF + (((size_t)c.row_pitch + 15u) & ~(size_t)15u);
+		if (clds > 160u * 1024u)
+			return -E2BIG;
+		if (clds > 48u * 1024u)
+			HIP_TRY(hipFuncSetAttribute(
+				(const void *)h264_amd_k_decode_cabac_subset,
+				hipFuncAttributeMaxDynamicSharedMemorySize, (int)clds));
+		HIP_TRY(hipEventRecord(e->ev[FAM_CABAC][0], e->stream));
+		hipLaunchKernelGGL(h264_amd_k_decode_cabac_subset, dim3(c.n), dim3(64),
+				   clds, e->stream, c);
+		HIP_TRY(hipGetLastError());
+		HIP_TRY(hipEventRecord(e->ev[FAM_CABAC][1], e->stream));
+		e->timed[FAM_CABAC] = true;
+	}
 	return 0;
 }
 

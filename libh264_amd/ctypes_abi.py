@@ -352,4 +352,5 @@ class GenSlice(S):
 
 TIER_NONE, TIER_T0, TIER_T1, TIER_T2 = 0, 1, 2, 3
 READER_FLAGS_SLICE_DATA = 1
+READER_FLAGS_CABAC_SUBSET = 0x100  # engine extension, see h264_amd.h
 SR_HEADER_OK, SR_DATA_PARSED, SR_CABAC = 1, 2, 4

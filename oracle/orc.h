@@ -308,6 +308,9 @@ void orc_mb_to_record(const struct orc_ctx *ctx, uint8_t *rec, uint32_t stride);
  *      src/h264_cabac.c, src/h264_cabac_ctx_tables.c, src/h264_writer.c) */
 void orc_cabac_init_states(int slice_type, uint32_t cabac_init_idc,
 			   int32_t SliceQPLuma, uint8_t states[1024][2]);
+/* engine extension (no reference behaviour): CABAC decode of the syntax the
+ * reference's writers emit, see orc_cabac.c */
+int orc_cabac_subset_slice_data(struct h264_bitstream *bs, struct orc_reader *rd);
 int orc_write_grey_i_slice(struct h264_bitstream *bs, struct orc_ctx *ctx,
 			   uint32_t mb_count);
 int orc_write_skipped_p_slice(struct h264_bitstream *bs, struct orc_ctx *ctx,

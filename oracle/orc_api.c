@@ -342,7 +342,9 @@ int orc_rec_parse_nalu(struct orc_rec *r, const uint8_t *base,
 			if (cabac)
 				sr.flags |= H264_AMD_SR_CABAC;
 			if ((r->flags & H264_READER_FLAGS_SLICE_DATA) &&
-			    !cabac && res != H264_AMD_E_UNSUPPORTED)
+			    (!cabac ||
+			     (r->flags & H264_AMD_READER_FLAGS_CABAC_SUBSET)) &&
+			    res != H264_AMD_E_UNSUPPORTED)
 				sr.flags |= H264_AMD_SR_DATA_PARSED;
 			sr.slice_type = ctx->slice.type;
 			sr.first_mb_in_slice = ctx->slice.hdr.first_mb_in_slice;

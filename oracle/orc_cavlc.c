@@ -965,8 +965,13 @@ static int slice_data_internal(struct h264_bitstream *bs, struct orc_reader *rd)
 	uint32_t addr, mb_count = 0, skip_run = 0, i;
 	int res;
 
-	if (ctx->pps->entropy_coding_mode_flag)
-		return 0; /* CABAC is not parsed (Appendix C.1) */
+	if (ctx->pps->entropy_coding_mode_flag) {
+		/* CABAC is not parsed (Appendix C.1) unless the engine's subset
+		 * decoder is asked for */
+		if (rd->flags & H264_AMD_READER_FLAGS_CABAC_SUBSET)
+			return orc_cabac_subset_slice_data(bs, rd);
+		return 0;
+	}
 	if (ctx->derived.MbaffFrameFlag || ctx->pps->num_slice_groups_minus1 > 0)
 		return H264_AMD_E_UNSUPPORTED;
 
