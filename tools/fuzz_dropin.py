@@ -60,6 +60,9 @@ def main():
         if msg:
             print(msg, flush=True)
             bad += 1
+        if (seed - first) % 100 == 99:  # a sign of life for the job runner
+            print("... %d seeds, %d divergences" % (seed - first + 1, bad),
+                  flush=True)
     print("seeds %d..%d divergences: %d" % (first, first + count - 1, bad))
 
 
