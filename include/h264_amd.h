@@ -125,12 +125,20 @@ static inline uint32_t h264_amd_t2_stride(uint32_t chroma_array_type)
 #define H264_AMD_SR_CABAC 0x0004 /* CABAC slice: data kept raw */
 
 /* Engine-specific status values besides negative errno */
-#define H264_AMD_E_UNSUPPORTED (-ENOSYS) /* MBAFF / FMO; CABAC beyond the subset */
+#define H264_AMD_E_UNSUPPORTED (-ENOSYS) /* MBAFF / FMO; CABAC beyond the subset; absurd widths */
 #define H264_AMD_E_MB_OVERFLOW (-EOVERFLOW) /* more MBs than mb_capacity */
 /* Most macroblocks one slice may deliver (64 pictures of 4096 x 2304): where the
  * drop-in reader stops growing a slice's record area, and where the oracle
  * stops too.  Only a damaged mb_skip_run gets anywhere near. */
 #define H264_AMD_MAX_SLICE_MBS (1u << 22)
+
+/* Widest picture whose slice data is walked, in macroblocks (16896 pixels).
+ * Level 6.2, the highest there is, allows PicWidthInMbs <= sqrt(8 * MaxFS) =
+ * 1055; the reference itself accepts any 32-bit width (and divides by a width
+ * of 0, src/h264_macroblock.c:318-330).  Slices of wider pictures, and of
+ * pictures of width 0, end with H264_AMD_E_UNSUPPORTED in product and oracle
+ * alike; their headers are still parsed.  Bounds the per-wave row context. */
+#define H264_AMD_MAX_PIC_WIDTH_MBS 1056u
 
 /* Per-slice outcome, 64 bytes.  status mirrors what _h264_read_nalu would
  * have returned for this NAL (0, -EIO, -EINVAL ...). */

@@ -573,7 +573,14 @@ extern "C" int h264_amd_decode_slices(struct h264_amd_engine *e,
 	a.results = args->d_results;
 	a.headers = args->d_headers;
 	a.mb_out = args->d_mb_out;
-	a.row_pitch = params->max_width_mbs;
+	/* row context only where slice data is walked, and never for more
+	 * columns than H264_AMD_MAX_PIC_WIDTH_MBS: one damaged SPS must not make
+	 * the whole batch unlaunchable (it used to: -E2BIG for every slice) */
+	a.row_pitch = 1;
+	if (args->reader_flags & H264_READER_FLAGS_SLICE_DATA)
+		a.row_pitch = params->max_width_mbs < H264_AMD_MAX_PIC_WIDTH_MBS
+				      ? params->max_width_mbs
+				      : H264_AMD_MAX_PIC_WIDTH_MBS;
 
 	a.wave_lds_bytes = (SD_ROW_OFF + 16u * a.row_pitch + 255u) & ~255u;
 	size_t lds = SD_TABS_BYTES + (size_t)SD_WAVES_PER_BLOCK * a.wave_lds_bytes;

@@ -472,6 +472,9 @@ int orc_cabac_subset_slice_data(struct h264_bitstream *bs, struct orc_reader *rd
 
 	if (ctx->derived.MbaffFrameFlag || ctx->pps->num_slice_groups_minus1 > 0)
 		return H264_AMD_E_UNSUPPORTED;
+	if (ctx->sps_derived.PicWidthInMbs == 0 ||
+	    ctx->sps_derived.PicWidthInMbs > H264_AMD_MAX_PIC_WIDTH_MBS)
+		return H264_AMD_E_UNSUPPORTED;
 	cabac_tables_init();
 	if (rd->cbs.slice_data_begin)
 		rd->cbs.slice_data_begin(ctx, sh, rd->userdata);

@@ -247,3 +247,57 @@ def test_hostile_sps_field_widths(engine, fn4, poc4):
         assert osizes[i] == w.len, (i, osizes[i], w.len)
         got = raw[int(ooffs[i]):int(ooffs[i]) + w.len].tobytes()
         assert got == ref_w.rewrites[w.off:w.off + w.len], i
+
+
+def test_absurd_picture_widths(engine):
+    """A damaged SPS can carry any 32-bit width (the drop-in fuzz found one of
+    65408 pixels that made the whole batch unlaunchable, -E2BIG).  Slice data
+    is walked up to H264_AMD_MAX_PIC_WIDTH_MBS columns; wider pictures and
+    width 0 (only reachable through h264_ctx_set_sps; the reference divides
+    by it) end with
+    H264_AMD_E_UNSUPPORTED, their headers parsed, other slices of the batch
+    untouched -- and a header-only parse does not care about the width."""
+    from libh264_amd.ctypes_abi import SliceHeader
+    b = orc.Builder()
+    cfg = streams.small_cfg()
+    good = [gen.slice_nal(cfg, streams.rich_slice(cfg, s, 2)) for s in range(3)]
+    nals = [gen.sps(cfg), gen.pps(cfg)] + good
+    for sps_id, wm1 in ((1, 1055), (2, 1056), (3, 4087), (4, 0xfffffffe)):
+        sps = orc.parse_nalus([gen.sps(cfg)]).sps[0]
+        sps = type(sps).from_buffer_copy(bytes(sps))
+        sps.seq_parameter_set_id = sps_id
+        sps.pic_width_in_mbs_minus1 = wm1
+        sps.pic_height_in_map_units_minus1 = 0
+        pps = orc.parse_nalus([gen.sps(cfg), gen.pps(cfg)]).pps[0]
+        pps = type(pps).from_buffer_copy(bytes(pps))
+        pps.pic_parameter_set_id = 10 + sps_id
+        pps.seq_parameter_set_id = sps_id
+        nals += [b.nalu(3, 7, sps=sps), b.nalu(3, 8, sps=sps, pps=pps)]
+        # a slice of that picture: take a good slice's bytes, re-head it
+        donor = streams.rich_slice(cfg, 9, 2, num_mbs=6, hdr_extras=0)
+        c2 = streams.small_cfg(width_mbs=8, height_mbs=6)
+        c2.pps_id = 10 + sps_id
+        nals.append(gen.slice_nal(c2, donor))
+    for flags in (1, 0):
+        ref = orc.parse_nalus(nals, flags=flags)
+        assert all(s == 0 for s in ref.statuses[:5])
+        sl = [n for n in nals if (n[0] & 0x1f) in (1, 5)]
+        params = make_params(ref)
+        buf, offs, sizes = streams.pack_nals(sl)
+        d_buf = engine.upload(buf)
+        descs = [(o, s, params.epoch) for o, s in zip(offs, sizes)]
+        out = engine.decode_slices(params, d_buf, descs, reader_flags=flags,
+                                   tier=TIER_T2 if flags else TIER_NONE,
+                                   mb_capacity=64, want_headers=True)
+        res = engine.fetch_results(out)
+        got = [result_fields(r) for r in res]
+        want = [result_fields(r) for r in ref.results]
+        assert got == want
+        st = [r.status for r in res]
+        if flags:
+            assert st[:3] == [0, 0, 0] and st[4:] == [-38, -38, -38], st
+            for i in range(3):
+                mb = engine.fetch_mb(out, i, res[i].mb_count)
+                assert np.array_equal(mb[:, :t2_stride(1)], ref.mb_records(i))
+        else:
+            assert st == [0] * 7
