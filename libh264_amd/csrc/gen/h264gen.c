@@ -239,7 +239,9 @@ int h264gen_sps(const struct h264gen_cfg *c, uint8_t *out, size_t cap)
 	bw_u(&w, 0, 1); /* gaps_in_frame_num_value_allowed_flag */
 	bw_ue(&w, c->width_mbs - 1);
 	bw_ue(&w, c->height_mbs - 1);
-	bw_u(&w, 1, 1); /* frame_mbs_only_flag */
+	bw_u(&w, c->field_coding ? 0 : 1, 1); /* frame_mbs_only_flag */
+	if (c->field_coding)
+		bw_u(&w, c->field_coding == 2, 1); /* mb_adaptive_frame_field_flag */
 	bw_u(&w, c->direct_8x8_inference_flag, 1);
 	if (c->crop_bottom) {
 		bw_u(&w, 1, 1);
@@ -617,11 +619,15 @@ static void put_residual(struct gen *g, uint32_t i, int i16, uint32_t cbp_luma,
 	}
 }
 
+/* field pictures: every macroblock record carries the field flag (0x04) */
+static __thread uint32_t t_field_flag;
+
 static void rec_head(uint8_t *rec, uint32_t mb_type, uint32_t cbp,
 		     uint32_t flags, uint32_t raw, int32_t qpd)
 {
 	if (!rec)
 		return;
+	flags |= t_field_flag;
 	rec[0] = (uint8_t)mb_type;
 	rec[1] = (uint8_t)cbp;
 	rec[2] = (uint8_t)flags;
@@ -897,11 +903,17 @@ static void put_slice_header(struct gen *g)
 	bw_ue(w, s->slice_type);
 	bw_ue(w, c->pps_id);
 	bw_u_wide(w, s->frame_num, c->log2_max_frame_num_minus4 + 4u);
+	if (c->field_coding) {
+		bw_u(w, s->field_pic != 0, 1); /* field_pic_flag */
+		if (s->field_pic)
+			bw_u(w, s->field_pic == 2, 1); /* bottom_field_flag */
+	}
 	if (s->idr)
 		bw_ue(w, s->idr_pic_id);
 	if (c->pic_order_cnt_type == 0) {
 		bw_u_wide(w, s->poc_lsb, c->log2_max_poc_lsb_minus4 + 4u);
-		if (c->bottom_field_pic_order_in_frame_present_flag)
+		if (c->bottom_field_pic_order_in_frame_present_flag &&
+		    !(c->field_coding && s->field_pic))
 			bw_se(w, 0);
 	}
 	if (c->redundant_pic_cnt_present_flag)
@@ -1034,6 +1046,7 @@ int h264gen_slice_nal(const struct h264gen_cfg *cfg,
 			  : cfg->num_ref_idx_l1_default_minus1;
 	g.t2 = t2;
 	g.t2_stride = t2_stride;
+	t_field_flag = (cfg->field_coding && sl->field_pic) ? 0x04u : 0u;
 	bw_init(&g.w, out, cap);
 	put_slice_header(&g);
 

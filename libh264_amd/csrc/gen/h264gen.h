@@ -44,6 +44,10 @@ struct h264gen_cfg {
 	uint32_t bottom_field_pic_order_in_frame_present_flag;
 	uint32_t constrained_intra_pred_flag;
 	uint32_t vui; /* 1: emit a VUI with timing + HRD-less restriction info */
+	/* 0: frame_mbs_only_flag = 1; 1: interlaced material without MBAFF
+	 * (height_mbs = map units of one FIELD); 2: same with
+	 * mb_adaptive_frame_field_flag = 1 */
+	uint32_t field_coding;
 };
 
 #define H264GEN_HDR_RPLM 0x1 /* ref_pic_list_modification entries */
@@ -70,6 +74,7 @@ struct h264gen_slice {
 	uint32_t pm_cbp_zero; /* coded MBs without residual */
 	uint32_t end_with_skip; /* finish a P/B slice on an mb_skip_run */
 	uint32_t cabac_payload; /* CABAC PPS: bytes of opaque slice data */
+	uint32_t field_pic; /* field_coding != 0: 0 frame picture, 1 top, 2 bottom field */
 	uint64_t seed;
 };
 

@@ -140,8 +140,8 @@ __device__ __forceinline__ uint32_t cb_hdr(const struct h264_slice_header *h,
 __device__ __forceinline__ int
 cb_slice_data(WaveBits &wb, const BacTabs &bt, uint16_t *ctx, uint8_t *stage,
 	      uint8_t *row, OutCtx &o, uint32_t lane, uint32_t type, uint32_t cat,
-	      uint32_t W, uint32_t first_mb, uint32_t mb_capacity,
-	      uint32_t &mb_count)
+	      uint32_t W, uint32_t first_mb, uint32_t field_pic,
+	      uint32_t mb_capacity, uint32_t &mb_count)
 {
 	BacDec d;
 	d.eof = 0;
@@ -161,10 +161,12 @@ cb_slice_data(WaveBits &wb, const BacTabs &bt, uint16_t *ctx, uint8_t *stage,
 
 	const bool is_i = type == H264_SLICE_TYPE_I, is_si = type == H264_SLICE_TYPE_SI;
 	const uint32_t skip_off = type == H264_SLICE_TYPE_B ? 24u : 11u;
+	/* field pictures: every macroblock carries the picture's flag */
+	const uint32_t field_flag = field_pic ? (uint32_t)H264_AMD_MB_FIELD : 0u;
 	const uint32_t skip_word0 =
 		(type == H264_SLICE_TYPE_B ? (uint32_t)H264_MB_TYPE_B_SKIP
 					   : (uint32_t)H264_MB_TYPE_P_SKIP) |
-		((uint32_t)H264_AMD_MB_SKIPPED << 16);
+		(((uint32_t)H264_AMD_MB_SKIPPED | field_flag) << 16);
 	uint32_t mbx = first_mb % W, mbidx = 0;
 	uint32_t left = 0; /* neighbour byte of the previous macroblock */
 	uint32_t prev_qp_nonzero = 0;
@@ -270,7 +272,8 @@ cb_slice_data(WaveBits &wb, const BacTabs &bt, uint16_t *ctx, uint8_t *stage,
 				return H264_AMD_E_UNSUPPORTED; /* residual */
 
 			/* record: 8 bytes of summary, zeros behind them */
-			uint32_t word0 = (uint32_t)H264_MB_TYPE_I_16x16 | ((1u + pred) << 24);
+			uint32_t word0 = (uint32_t)H264_MB_TYPE_I_16x16 | (field_flag << 16) |
+					 ((1u + pred) << 24);
 			uint32_t word1 = ((uint32_t)qpd & 0xffffu) | (chroma << 16) |
 					 (pred << 24);
 			*reinterpret_cast<uint32_t *>(stage) = word0;
@@ -337,8 +340,8 @@ h264_amd_k_decode_cabac_subset(cb_args a)
 				     a.ppsv, a.epochs + e, a.n_sps, a.n_pps);
 	}
 	const uint32_t W = r.pic_width_in_mbs;
+	const uint32_t field_pic = cb_hdr(hdr, WOFF(field_pic_flag));
 	if (status == 0) {
-		const uint32_t field_pic = cb_hdr(hdr, WOFF(field_pic_flag));
 		if ((P.sps.mb_adaptive_frame_field_flag && !field_pic) ||
 		    P.pps.num_slice_groups_minus1 > 0 || W == 0 || W > a.row_pitch)
 			status = H264_AMD_E_UNSUPPORTED;
@@ -385,7 +388,7 @@ h264_amd_k_decode_cabac_subset(cb_args a)
 		}
 		status = cb_slice_data(wb, bt, ctx, stage, row, o, lane, type,
 				       r.chroma_array_type, W, r.first_mb_in_slice,
-				       a.mb_capacity, mb_count);
+				       field_pic, a.mb_capacity, mb_count);
 	}
 
 	/* T0: flush the partial last group of 64 words */

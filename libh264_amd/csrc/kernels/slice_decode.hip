@@ -254,7 +254,9 @@ sd_slice_header(WaveBits &wb, uint32_t lane, uint8_t *stage, SliceState &S,
 	S.W = sps.pic_width_in_mbs;
 	S.bdl = sps.bit_depth_luma;
 	S.bdc = sps.bit_depth_chroma;
-	S.pcm_chroma = S.cat == 0 ? 0u : S.cat == 1 ? 64u : S.cat == 2 ? 128u : 256u;
+	/* MbWidthC * MbHeightC; 0 for a chroma_format_idc above 3, which the
+	 * reference does not refuse (src/h264.c:46-71) */
+	S.pcm_chroma = S.cat == 1 ? 64u : S.cat == 2 ? 128u : S.cat == 3 ? 256u : 0u;
 	S.t8x8_mode = pps.transform_8x8_mode_flag;
 	S.direct8x8 = sps.direct_8x8_inference_flag;
 	S.entropy = pps.entropy_coding_mode_flag;
@@ -912,9 +914,12 @@ sd_slice_data(WaveBits &wb, const VlcTabs &vt, uint32_t cbp_map, uint32_t lane,
 	sd_mb_consts(m, lane, cat);
 	uint32_t mbx = S.first_mb % W;
 	uint32_t mbidx = 0;
+	/* field pictures: every macroblock carries the picture's flag
+	 * (ref src/h264_slice_data.c:1145-1149) */
+	const uint32_t field_flag = S.field_pic ? (uint32_t)H264_AMD_MB_FIELD : 0u;
 	const uint32_t skip_word0 =
 		(is_b ? (uint32_t)H264_MB_TYPE_B_SKIP : (uint32_t)H264_MB_TYPE_P_SKIP) |
-		((uint32_t)H264_AMD_MB_SKIPPED << 16);
+		(((uint32_t)H264_AMD_MB_SKIPPED | field_flag) << 16);
 
 	do {
 		wb_sync(wb, lane);
@@ -1026,7 +1031,7 @@ sd_slice_data(WaveBits &wb, const VlcTabs &vt, uint32_t cbp_map, uint32_t lane,
 			}
 		}
 
-		uint32_t flags = 0, icp = 0;
+		uint32_t flags = field_flag, icp = 0;
 		int32_t qpd = 0;
 		uint32_t pred_lo = 0, pred_hi = 0; /* pred[8] of the summary */
 

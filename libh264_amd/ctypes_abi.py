@@ -281,7 +281,7 @@ REFERENCE_SIZEOF = {
 
 
 def t2_stride(cat):
-    return 256 + 2 * {0: 256, 1: 384, 2: 512, 3: 768}[cat]
+    return 256 + 2 * {0: 256, 1: 384, 2: 512}.get(cat, 768)
 
 
 # ---- engine argument blocks and generator structs --------------------------
@@ -333,7 +333,7 @@ class GenCfg(S):
             "weighted_pred_flag weighted_bipred_idc "
             "redundant_pic_cnt_present_flag "
             "bottom_field_pic_order_in_frame_present_flag "
-            "constrained_intra_pred_flag vui").split()])
+            "constrained_intra_pred_flag vui field_coding").split()])
 
 
 class GenSlice(S):
@@ -346,7 +346,7 @@ class GenSlice(S):
             "num_ref_idx_l0_minus1 num_ref_idx_l1_minus1 cabac_init_idc "
             "hdr_extras pm_i16x16 pm_pcm pm_skip pm_intra_in_inter pm_t8x8 "
             "pm_escape pm_zero_pcm density pm_cbp_zero end_with_skip "
-            "cabac_payload").split()] +
+            "cabac_payload field_pic").split()] +
         [("seed", u64)])
 
 

@@ -355,8 +355,12 @@ int orc_rec_parse_nalu(struct orc_rec *r, const uint8_t *base,
 			sr.rawdata_len = (uint32_t)ctx->slice.rawdata.len;
 			sr.partial = ctx->slice.rawdata.partial;
 			sr.partialbits = ctx->slice.rawdata.partialbits;
-			sr.chroma_array_type =
-				(uint16_t)ctx->sps_derived.ChromaArrayType;
+			/* chroma_format_idc is not range-checked by the
+			 * reference: reported saturating, as the kernels keep it */
+			sr.chroma_array_type = (uint16_t)(
+				ctx->sps_derived.ChromaArrayType < 255
+					? ctx->sps_derived.ChromaArrayType
+					: 255);
 			sr.pic_width_in_mbs = ctx->sps_derived.PicWidthInMbs;
 			if (res == 0)
 				sr.end_bit =

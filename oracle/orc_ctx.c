@@ -15,10 +15,14 @@
 
 #define ORC_MIN(a, b) ((a) < (b) ? (a) : (b))
 
+/* Deviation (product, kernels and oracle alike): the reference's loop shifts a
+ * 32-bit value by 32 once x >= 2^31 -- undefined, and an endless loop on x86
+ * (reachable from a damaged SPS/PPS: slice_group_change_cycle width,
+ * src/h264_syntax.h:1365-1378).  Here the answer is the mathematical one. */
 uint32_t orc_intlog2(uint32_t x)
 {
 	uint32_t r = 0;
-	while ((x >> r) > 0)
+	while (r < 32 && (x >> r) > 0)
 		r++;
 	if (r > 0 && x == (1u << (r - 1)))
 		r--;

@@ -301,3 +301,25 @@ def test_absurd_picture_widths(engine):
                 assert np.array_equal(mb[:, :t2_stride(1)], ref.mb_records(i))
         else:
             assert st == [0] * 7
+
+
+@pytest.mark.parametrize("tier", [TIER_T2, TIER_T0])
+def test_field_pictures(engine, tier):
+    """Interlaced material without MBAFF: field pictures (field_pic_flag = 1,
+    top and bottom) carry the field flag on every macroblock record, skipped
+    ones included (ref src/h264_slice_data.c:1145-1149); frame pictures of the
+    same stream do not; with mb_adaptive_frame_field_flag frame pictures are
+    MBAFF (unsupported) and field pictures still decode.  Found by
+    tools/fuzz_params.py: the kernels used to leave the flag clear."""
+    cfg = streams.small_cfg(field_coding=1,
+                            bottom_field_pic_order_in_frame_present_flag=1)
+    slices = [streams.rich_slice(cfg, 60 + seed, st, field_pic=fp)
+              for seed in range(6) for st in (2, 0, 1) for fp in (0, 1, 2)]
+    res = run_case(engine, cfg, slices, tier)
+    cfg = streams.small_cfg(field_coding=2)
+    slices = [streams.rich_slice(cfg, 80 + seed, st, field_pic=fp)
+              for seed in range(3) for st in (2, 0, 1) for fp in (1, 2)]
+    run_case(engine, cfg, slices, tier)
+    mbaff = [gen.slice_nal(cfg, streams.rich_slice(cfg, 90, 2, field_pic=0))]
+    ref = orc.parse_nalus([gen.sps(cfg), gen.pps(cfg)] + mbaff)
+    assert ref.statuses[2] == -38

@@ -80,3 +80,18 @@ def test_1080p_slice():
                      num_mbs=8160, density=6, pm_i16x16=280, pm_pcm=20,
                      pm_escape=10, seed=42)
     roundtrip(cfg, [s])
+
+
+def test_field_pictures():
+    """interlaced material without MBAFF: frame, top-field and bottom-field
+    pictures; every macroblock of a field picture carries the field flag"""
+    cfg = streams.small_cfg(field_coding=1,
+                            bottom_field_pic_order_in_frame_present_flag=1)
+    slices = [streams.rich_slice(cfg, 60 + seed, st, field_pic=fp)
+              for seed in range(4) for st in (2, 0, 1) for fp in (0, 1, 2)]
+    rec = roundtrip(cfg, slices)
+    for i, s in enumerate(slices):
+        flag = rec.mb_records(i)[:, 2] & 4
+        assert (flag == (4 if s.field_pic else 0)).all()
+        assert rec.headers[i].field_pic_flag == (s.field_pic != 0)
+        assert rec.headers[i].bottom_field_flag == (s.field_pic == 2)
