@@ -139,7 +139,9 @@ def one(engine, seed):
         nal = gen.slice_nal(cfg, s)
         slice_pos.append(len(nals))
         nals.append(mutate(nal, rnd) if k % 4 == 1 else nal)
-    flags = rnd.choice([1, 1, 1, 0])
+    # 0x100: the engine's CABAC subset decoder (a hostile PPS turns CAVLC
+    # slices into 'CABAC' ones: error paths of the arithmetic decoder)
+    flags = rnd.choice([1, 1, 0x101, 0x101, 0])
     ref = orc.parse_nalus(nals, flags=flags)
     sl = [nals[i] for i in slice_pos]
     # every slice binds to the parameter sets current at ITS position
@@ -162,6 +164,8 @@ def one(engine, seed):
     descs = [(o, s, epochs[p]) for o, s, p in zip(offs, sizes, slice_pos)]
     cap = 4 * total
     tier = TIER_T2 if flags else TIER_NONE
+    if flags == 0:
+        ref_w = orc.parse_nalus(nals, flags=0, want=orc.ORC_REC_WANT_REWRITE)
     out = engine.decode_slices(params, d_buf, descs, reader_flags=flags,
                                tier=tier, mb_capacity=cap, want_headers=True)
     res = engine.fetch_results(out)
@@ -187,6 +191,28 @@ def one(engine, seed):
             mb = engine.fetch_mb(out, i, want["mb_count"])[:, :st]
             if not np.array_equal(mb, ref.mb_records(i)):
                 return "seed %d slice %d records differ" % (seed, i)
+    if flags == 0:
+        # write-back of every parsed header under the hostile parameters:
+        # same bytes as the oracle's h264_write_nalu restatement, or the same
+        # refusal
+        d_out, ooffs, osizes = engine.write_slices(params, d_buf, out,
+                                                   int(max(sizes)) + 4200)
+        raw = engine.download(d_out)
+        rew = {w.nal_index: w for w in ref_w.rewrite_idx}
+        for i, p in enumerate(slice_pos):
+            if res[i].status != 0 or p not in rew:
+                continue
+            w = rew[p]
+            if w.res < 0:
+                if int(osizes[i]) != w.res:
+                    return "seed %d slice %d write status %d != %d" % (
+                        seed, i, int(osizes[i]), w.res)
+                continue
+            got = raw[int(ooffs[i]):int(ooffs[i]) + max(int(osizes[i]), 0)]
+            if int(osizes[i]) != w.len or \
+                    got.tobytes() != ref_w.rewrites[w.off:w.off + w.len]:
+                return "seed %d slice %d (nal %d) write-back differs (%d vs " \
+                       "%d bytes)" % (seed, i, p, int(osizes[i]), w.len)
     return None
 
 
