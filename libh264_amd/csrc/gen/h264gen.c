@@ -362,7 +362,8 @@ struct gen {
 	struct bw w;
 	struct rng r;
 	uint32_t cat, W;
-	uint32_t st; /* slice type mod 5 */
+	uint32_t st; /* syntax class: 0 P (and SP), 1 B, 2 I (and SI) */
+	int sp, si; /* slice_type % 5 == 3 / == 4 */
 	uint32_t nref0, nref1; /* num_ref_idx_lX_active_minus1 */
 	uint8_t *nz; /* [num_mbs][48] */
 	uint8_t *t2;
@@ -688,15 +689,19 @@ static void put_intra_mb(struct gen *g, uint32_t i, uint32_t base, uint8_t *rec)
 		put_residual(g, i, 1, luma, chroma, rec);
 		return;
 	}
-	/* I_NxN */
+	/* I_NxN, or the SI macroblock (mb_type 0) of an SI slice: Intra_4x4
+	 * prediction, no transform flag in front of the prediction modes but,
+	 * as for every macroblock that is not I_NxN, behind a coded_block_pattern
+	 * with luma (7.3.5; ref src/h264_syntax_slice_data.h:662-682) */
 	{
-		int t8 = g->c->transform_8x8_mode_flag &&
+		int si_mb = g->si && rng_pm(&g->r, 300);
+		int t8 = !si_mb && g->c->transform_8x8_mode_flag &&
 			 rng_pm(&g->r, g->s->pm_t8x8);
 		uint32_t luma, chroma, cbp, icp = 0;
 		int32_t qpd = 0;
 		int no_res = rng_pm(&g->r, g->s->pm_cbp_zero);
-		bw_ue(w, base + 0);
-		if (g->c->transform_8x8_mode_flag)
+		bw_ue(w, si_mb ? 0 : base + 0);
+		if (!si_mb && g->c->transform_8x8_mode_flag)
 			bw_u(w, (uint32_t)t8, 1);
 		n = t8 ? 4 : 16;
 		for (b = 0; b < n; b++) {
@@ -718,11 +723,16 @@ static void put_intra_mb(struct gen *g, uint32_t i, uint32_t base, uint8_t *rec)
 		chroma = (no_res || !(g->cat == 1 || g->cat == 2)) ? 0 : rng_below(&g->r, 3);
 		cbp = luma | (chroma << 4);
 		bw_ue(w, s_cbp_code[(g->cat == 1 || g->cat == 2) ? 0 : 1][0][cbp]);
+		if (si_mb && luma > 0 && g->c->transform_8x8_mode_flag) {
+			t8 = rng_pm(&g->r, g->s->pm_t8x8);
+			bw_u(w, (uint32_t)t8, 1);
+		}
 		if (cbp) {
 			qpd = pick_qpd(g);
 			bw_se(w, qpd);
 		}
-		rec_head(rec, MB_I_NxN, cbp, t8 ? MBF_T8X8 : 0, base + 0, qpd);
+		rec_head(rec, si_mb ? MB_SI : MB_I_NxN, cbp, t8 ? MBF_T8X8 : 0,
+			 si_mb ? 0 : base + 0, qpd);
 		if (rec)
 			rec[6] = (uint8_t)icp;
 		if (cbp)
@@ -995,9 +1005,13 @@ static void put_slice_header(struct gen *g)
 			bw_u(w, 0, 1);
 		}
 	}
-	if (c->entropy_coding_mode_flag && g->st != 2 && g->st != 4)
+	if (c->entropy_coding_mode_flag && g->st != 2)
 		bw_ue(w, s->cabac_init_idc);
 	bw_se(w, s->slice_qp_delta);
+	if (g->sp)
+		bw_u(w, rng_below(&g->r, 2), 1); /* sp_for_switch_flag */
+	if (g->sp || g->si)
+		bw_se(w, (int32_t)rng_below(&g->r, 21) - 10); /* slice_qs_delta */
 	if (c->deblocking_filter_control_present_flag) {
 		bw_ue(w, s->disable_deblocking_filter_idc);
 		if (s->disable_deblocking_filter_idc != 1) {
@@ -1038,6 +1052,9 @@ int h264gen_slice_nal(const struct h264gen_cfg *cfg,
 	g.cat = chroma_array_type(cfg);
 	g.W = cfg->width_mbs;
 	g.st = sl->slice_type % 5;
+	g.sp = g.st == 3;
+	g.si = g.st == 4;
+	g.st = g.sp ? 0 : g.si ? 2 : g.st;
 	g.nref0 = (sl->hdr_extras & H264GEN_HDR_OVERRIDE)
 			  ? sl->num_ref_idx_l0_minus1
 			  : cfg->num_ref_idx_l0_default_minus1;
@@ -1068,7 +1085,7 @@ int h264gen_slice_nal(const struct h264gen_cfg *cfg,
 	for (i = 0; i < sl->num_mbs; i++) {
 		uint8_t *rec = rec_of(&g, i);
 		if (g.st == 2) {
-			put_intra_mb(&g, i, 0, rec);
+			put_intra_mb(&g, i, g.si ? 1 : 0, rec);
 			if (rec)
 				memcpy(rec + 16, g.nz + (size_t)i * 48, 48);
 			continue;

@@ -323,3 +323,13 @@ def test_field_pictures(engine, tier):
     mbaff = [gen.slice_nal(cfg, streams.rich_slice(cfg, 90, 2, field_pic=0))]
     ref = orc.parse_nalus([gen.sps(cfg), gen.pps(cfg)] + mbaff)
     assert ref.statuses[2] == -38
+
+
+@pytest.mark.parametrize("cf", [1, 3])
+def test_sp_and_si_slices(engine, cf):
+    cfg = streams.small_cfg(cf=cf, weighted_pred_flag=1)
+    slices = [streams.rich_slice(cfg, 70 + seed, st, first_mb=seed % 5)
+              for seed in range(8) for st in (3, 4, 8, 9)]
+    run_case(engine, cfg, slices, TIER_T2)
+    roundtrip = __import__("test_gpu_scan_write").roundtrip_case
+    roundtrip(engine, cfg, slices[:12])

@@ -95,3 +95,18 @@ def test_field_pictures():
         assert (flag == (4 if s.field_pic else 0)).all()
         assert rec.headers[i].field_pic_flag == (s.field_pic != 0)
         assert rec.headers[i].bottom_field_flag == (s.field_pic == 2)
+
+
+@pytest.mark.parametrize("cf", [1, 0, 2, 3])
+def test_sp_and_si_slices(cf):
+    """Extended-profile switching slices: SP (P syntax + sp_for_switch_flag +
+    slice_qs_delta) and SI (mb_type 0 = the SI macroblock, I types shifted by
+    one; transform_size_8x8_flag behind its coded_block_pattern)"""
+    cfg = streams.small_cfg(cf=cf, weighted_pred_flag=1)
+    slices = [streams.rich_slice(cfg, 70 + seed, st, first_mb=seed % 5)
+              for seed in range(8) for st in (3, 4, 8, 9)]
+    rec = roundtrip(cfg, slices)
+    kinds = set()
+    for i in range(len(slices)):
+        kinds |= set(rec.mb_records(i)[:, 0].tolist())
+    assert 4 in kinds  # H264_MB_TYPE_SI

@@ -33,7 +33,7 @@ def one(engine, seed):
     total = cfg.width_mbs * cfg.height_mbs
     nals = []
     for k in range(160):
-        st = rnd.choice([2, 0, 1, 7, 5, 6])
+        st = rnd.choice([2, 0, 1, 7, 5, 6, 3, 4])
         first = rnd.choice([0, 0, rnd.randrange(total - 1)])
         n = rnd.randrange(1, total - first + 1)
         s = streams.rich_slice(cfg, seed * 977 + k, st, first, n,

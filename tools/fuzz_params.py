@@ -129,7 +129,7 @@ def one(engine, seed):
                                    pps=hostile_pps(base.pps[0], rnd)))
             except OSError:
                 pass
-        st = rnd.choice([2, 0, 1, 7, 5, 6])
+        st = rnd.choice([2, 0, 1, 7, 5, 6, 3, 4])
         first = rnd.choice([0, 0, rnd.randrange(total - 1)])
         n = rnd.randrange(1, total - first + 1)
         s = streams.rich_slice(cfg, seed * 991 + k, st, first, n,
