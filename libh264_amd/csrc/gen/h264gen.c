@@ -233,8 +233,17 @@ int h264gen_sps(const struct h264gen_cfg *c, uint8_t *out, size_t cap)
 	}
 	bw_ue(&w, c->log2_max_frame_num_minus4);
 	bw_ue(&w, c->pic_order_cnt_type);
-	if (c->pic_order_cnt_type == 0)
+	if (c->pic_order_cnt_type == 0) {
 		bw_ue(&w, c->log2_max_poc_lsb_minus4);
+	} else if (c->pic_order_cnt_type == 1) {
+		bw_u(&w, c->delta_pic_order_always_zero_flag, 1);
+		bw_se(&w, -3); /* offset_for_non_ref_pic */
+		bw_se(&w, 1); /* offset_for_top_to_bottom_field */
+		bw_ue(&w, 3); /* num_ref_frames_in_pic_order_cnt_cycle */
+		bw_se(&w, 2);
+		bw_se(&w, -1);
+		bw_se(&w, 4);
+	}
 	bw_ue(&w, c->max_num_ref_frames);
 	bw_u(&w, 0, 1); /* gaps_in_frame_num_value_allowed_flag */
 	bw_ue(&w, c->width_mbs - 1);
@@ -924,7 +933,13 @@ static void put_slice_header(struct gen *g)
 		bw_u_wide(w, s->poc_lsb, c->log2_max_poc_lsb_minus4 + 4u);
 		if (c->bottom_field_pic_order_in_frame_present_flag &&
 		    !(c->field_coding && s->field_pic))
-			bw_se(w, 0);
+			bw_se(w, (int32_t)rng_below(&g->r, 9) - 4);
+	}
+	if (c->pic_order_cnt_type == 1 && !c->delta_pic_order_always_zero_flag) {
+		bw_se(w, (int32_t)rng_below(&g->r, 41) - 20);
+		if (c->bottom_field_pic_order_in_frame_present_flag &&
+		    !(c->field_coding && s->field_pic))
+			bw_se(w, (int32_t)rng_below(&g->r, 41) - 20);
 	}
 	if (c->redundant_pic_cnt_present_flag)
 		bw_ue(w, 0);

@@ -28,7 +28,7 @@ struct h264gen_cfg {
 	uint32_t chroma_format_idc; /* != 1 needs a High-family profile_idc */
 	uint32_t bit_depth_luma_minus8, bit_depth_chroma_minus8;
 	uint32_t log2_max_frame_num_minus4;
-	uint32_t pic_order_cnt_type; /* 0 or 2 */
+	uint32_t pic_order_cnt_type; /* 0, 1 or 2 */
 	uint32_t log2_max_poc_lsb_minus4;
 	uint32_t max_num_ref_frames;
 	uint32_t direct_8x8_inference_flag;
@@ -48,6 +48,7 @@ struct h264gen_cfg {
 	 * (height_mbs = map units of one FIELD); 2: same with
 	 * mb_adaptive_frame_field_flag = 1 */
 	uint32_t field_coding;
+	uint32_t delta_pic_order_always_zero_flag; /* pic_order_cnt_type 1 */
 };
 
 #define H264GEN_HDR_RPLM 0x1 /* ref_pic_list_modification entries */

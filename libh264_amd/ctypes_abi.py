@@ -333,7 +333,8 @@ class GenCfg(S):
             "weighted_pred_flag weighted_bipred_idc "
             "redundant_pic_cnt_present_flag "
             "bottom_field_pic_order_in_frame_present_flag "
-            "constrained_intra_pred_flag vui field_coding").split()])
+            "constrained_intra_pred_flag vui field_coding "
+            "delta_pic_order_always_zero_flag").split()])
 
 
 class GenSlice(S):

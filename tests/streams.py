@@ -74,14 +74,20 @@ def annexb(nals, long_codes=None):
     return bytes(out)
 
 
-def mixed_nals(cfg, n_slices=24, seed0=0, split=True):
+def mixed_nals(cfg, n_slices=24, seed0=0, split=True, types=(2, 0, 1, 0),
+               **slice_kw):
     """SPS, PPS, then pictures made of AUD + SEI + one or two slices, with a
-    filler now and then and a repeated parameter-set pair in the middle."""
+    filler now and then and a repeated parameter-set pair in the middle.
+    With cfg.field_coding pictures cycle frame / top field / bottom field."""
     nals = [gen.sps(cfg), gen.pps(cfg)]
     total = cfg.width_mbs * cfg.height_mbs
     for k in range(n_slices):
         seed = seed0 + k
-        st = (2, 0, 1, 0)[k % 4]
+        st = types[k % len(types)]
+        kw = dict(slice_kw)
+        if cfg.field_coding:
+            kw["field_pic"] = (0, 1, 2, 1, 2)[k % 5]
+            kw["frame_num"] = (k // 2) % 16
         if k % 3 == 0:
             nals.append(gen.aud(k % 3))
         if k % 5 == 0:
@@ -89,11 +95,11 @@ def mixed_nals(cfg, n_slices=24, seed0=0, split=True):
         if split and k % 2:
             half = total // 2
             nals.append(gen.slice_nal(
-                cfg, rich_slice(cfg, seed, st, 0, half)))
+                cfg, rich_slice(cfg, seed, st, 0, half, **kw)))
             nals.append(gen.slice_nal(
-                cfg, rich_slice(cfg, seed, st, half, total - half)))
+                cfg, rich_slice(cfg, seed, st, half, total - half, **kw)))
         else:
-            nals.append(gen.slice_nal(cfg, rich_slice(cfg, seed, st)))
+            nals.append(gen.slice_nal(cfg, rich_slice(cfg, seed, st, **kw)))
         if k % 7 == 3:
             nals.append(gen.filler(20 + k))
         if k == n_slices // 2:

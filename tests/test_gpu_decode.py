@@ -316,6 +316,7 @@ def test_field_pictures(engine, tier):
     slices = [streams.rich_slice(cfg, 60 + seed, st, field_pic=fp)
               for seed in range(6) for st in (2, 0, 1) for fp in (0, 1, 2)]
     res = run_case(engine, cfg, slices, tier)
+    __import__("test_gpu_scan_write").roundtrip_case(engine, cfg, slices)
     cfg = streams.small_cfg(field_coding=2)
     slices = [streams.rich_slice(cfg, 80 + seed, st, field_pic=fp)
               for seed in range(3) for st in (2, 0, 1) for fp in (1, 2)]
@@ -333,3 +334,16 @@ def test_sp_and_si_slices(engine, cf):
     run_case(engine, cfg, slices, TIER_T2)
     roundtrip = __import__("test_gpu_scan_write").roundtrip_case
     roundtrip(engine, cfg, slices[:12])
+
+
+@pytest.mark.parametrize("always_zero,field_coding", [(0, 0), (0, 1), (1, 1)])
+def test_pic_order_cnt_type_1(engine, always_zero, field_coding):
+    cfg = streams.small_cfg(pic_order_cnt_type=1,
+                            delta_pic_order_always_zero_flag=always_zero,
+                            bottom_field_pic_order_in_frame_present_flag=1,
+                            field_coding=field_coding)
+    slices = [streams.rich_slice(cfg, 70 + seed, st,
+                                 field_pic=seed % 3 if field_coding else 0)
+              for seed in range(8) for st in (2, 0, 1)]
+    run_case(engine, cfg, slices, TIER_T2)
+    __import__("test_gpu_scan_write").roundtrip_case(engine, cfg, slices)

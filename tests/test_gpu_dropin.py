@@ -91,6 +91,31 @@ def test_reader_stream_formats(cf, bd):
     same_log(ref, got, stream=True)
 
 
+@pytest.mark.parametrize("kw", [
+    dict(field_coding=1, bottom_field_pic_order_in_frame_present_flag=1),
+    dict(field_coding=1, pic_order_cnt_type=1),
+    dict(pic_order_cnt_type=1, delta_pic_order_always_zero_flag=1),
+    dict(field_coding=2),     # MBAFF frame pictures: -ENOSYS, fields decode
+])
+def test_reader_stream_interlaced_and_poc1(kw):
+    """field pictures (access-unit detection looks at field_pic_flag and
+    bottom_field_flag, 7.4.1.2.4; every macroblock callback of a field picture
+    belongs to a field macroblock), pic_order_cnt_type 1, SP / SI slices"""
+    cfg = streams.small_cfg(**kw)
+    nals = streams.mixed_nals(cfg, n_slices=20, seed0=70,
+                              types=(2, 0, 1, 3, 4))
+    data = streams.annexb(nals)
+    ref = orc.parse_stream(data, want=0)
+    got = prod.parse_stream(data)
+    assert got.consumed == ref.consumed
+    same_log(ref, got, stream=True)
+    ref = orc.parse_nalus(nals, want=0)
+    got = prod.parse_nalus(nals)
+    assert got.statuses == ref.statuses
+    assert (-38 in ref.statuses) == (kw.get("field_coding") == 2)
+    same_log(ref, got, stream=False)
+
+
 def test_reader_nalu_by_nalu_with_damage():
     """h264_reader_parse_nalu per NAL, statuses included; some NAL units are
     truncated, bit-flipped, empty, or carry the forbidden bit."""

@@ -110,3 +110,21 @@ def test_sp_and_si_slices(cf):
     for i in range(len(slices)):
         kinds |= set(rec.mb_records(i)[:, 0].tolist())
     assert 4 in kinds  # H264_MB_TYPE_SI
+
+
+@pytest.mark.parametrize("always_zero,field_coding", [(0, 0), (0, 1), (1, 1)])
+def test_pic_order_cnt_type_1(always_zero, field_coding):
+    cfg = streams.small_cfg(pic_order_cnt_type=1,
+                            delta_pic_order_always_zero_flag=always_zero,
+                            bottom_field_pic_order_in_frame_present_flag=1,
+                            field_coding=field_coding)
+    slices = [streams.rich_slice(cfg, 70 + seed, st,
+                                 field_pic=seed % 3 if field_coding else 0)
+              for seed in range(8) for st in (2, 0, 1)]
+    rec = roundtrip(cfg, slices)
+    assert rec.sps[0].num_ref_frames_in_pic_order_cnt_cycle == 3
+    d = [tuple(h.delta_pic_order_cnt) for h in rec.headers]
+    assert (set(d) == {(0, 0)}) == bool(always_zero)
+    for h, s in zip(rec.headers, slices):
+        if s.field_pic:
+            assert h.delta_pic_order_cnt[1] == 0
