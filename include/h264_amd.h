@@ -263,6 +263,19 @@ H264_API int h264_amd_scan(struct h264_amd_engine *eng,
 			   size_t *count,
 			   size_t *consumed);
 
+/* Head bytes of every NAL unit of a scan, as one dense table: d_heads[i][j] =
+ * d_buf[nal[i].start + j] for j < min(head_bytes, nal length), 0 beyond.  What
+ * the host control plane of a device-resident pipeline needs to see -- the NAL
+ * header byte (nal_ref_idc, nal_unit_type: src/h264_syntax.h:1434-1443) of
+ * every unit and the whole of short ones (parameter sets, AUD) -- in one
+ * device-to-host copy instead of one per NAL unit.  head_bytes: 1..256. */
+H264_API int h264_amd_gather_nal_heads(struct h264_amd_engine *eng,
+				       const uint8_t *d_buf,
+				       const struct h264_amd_nal *d_nals,
+				       size_t n,
+				       uint32_t head_bytes,
+				       uint8_t *d_heads);
+
 /* ---- slice decode -------------------------------------------------------- */
 /* reader_flags bit beside H264_READER_FLAGS_SLICE_DATA: also walk the slice
  * data of CABAC slices as far as the CABAC SUBSET goes.  The reference has no

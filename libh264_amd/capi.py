@@ -55,6 +55,7 @@ def engine_lib():
     L.h264_amd_params_epoch.argtypes = [vp]
     L.h264_amd_scan.argtypes = [vp, vp, sz, vp, sz, C.POINTER(sz),
                                 C.POINTER(sz)]
+    L.h264_amd_gather_nal_heads.argtypes = [vp, vp, vp, sz, u32, vp]
     L.h264_amd_decode_slices.argtypes = [vp, vp, C.POINTER(DecodeArgs)]
     L.h264_amd_write_slices.argtypes = [vp, vp, C.POINTER(WriteArgs)]
     L.h264_amd_encode_synth_slices.argtypes = [vp, vp, C.POINTER(SynthArgs)]
@@ -175,7 +176,7 @@ class Engine:
         return ms.value
 
     # -- scan -----------------------------------------------------------
-    def scan(self, d_buf, length, cap):
+    def scan(self, d_buf, length, cap, keep=False):
         d_nals = self.alloc(cap * C.sizeof(Nal))
         cnt, consumed = C.c_size_t(), C.c_size_t()
         _check(engine_lib().h264_amd_scan(self.h, d_buf.ptr, length,
@@ -183,7 +184,19 @@ class Engine:
                                           C.byref(consumed)), "scan")
         n = min(cnt.value, cap)
         tab = self.download(d_nals, n * C.sizeof(Nal), dtype=np.uint64)
+        if keep:  # also hand back the device table (for gather_nal_heads)
+            return tab.reshape(-1, 2), cnt.value, consumed.value, d_nals
         return tab.reshape(-1, 2), cnt.value, consumed.value
+
+    def gather_nal_heads(self, d_buf, d_nals, n, head_bytes=16):
+        """[n, head_bytes] uint8: the first bytes of every NAL unit."""
+        d_out = self.alloc(max(1, n * head_bytes))
+        _check(engine_lib().h264_amd_gather_nal_heads(
+            self.h, d_buf.ptr, d_nals.ptr, n, head_bytes, d_out.ptr),
+            "gather_nal_heads")
+        out = self.download(d_out, n * head_bytes)
+        d_out.free()
+        return out.reshape(n, head_bytes)
 
     # -- slice decode -----------------------------------------------------
     def decode_slices(self, params, d_buf, descs, reader_flags=1,

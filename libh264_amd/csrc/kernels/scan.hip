@@ -407,6 +407,21 @@ h264_amd_k_scan_place(scan_place_args a)
 	}
 }
 
+/* Head bytes of every NAL unit (h264_amd_gather_nal_heads): one thread per
+ * output byte, consecutive threads read consecutive bytes of one NAL unit. */
+extern "C" __global__ void __launch_bounds__(256)
+h264_amd_k_gather_heads(const uint8_t *buf, const struct h264_amd_nal *nals,
+			uint64_t n, uint32_t head, uint8_t *out)
+{
+	const uint64_t gid = (uint64_t)blockIdx.x * 256u + threadIdx.x;
+	if (gid >= n * head)
+		return;
+	const uint64_t i = gid / head;
+	const uint32_t j = (uint32_t)(gid % head);
+	const uint64_t s = nals[i].start, e = nals[i].end;
+	out[gid] = (e > s && j < e - s) ? buf[s + j] : (uint8_t)0;
+}
+
 static inline void scan_scratch_free(scan_scratch *s)
 {
 	hipFree(s->d_recs);

@@ -117,6 +117,36 @@ def test_scan_mixed_stream(engine):
     check_scan(engine, data)
 
 
+def test_gather_nal_heads(engine):
+    """first bytes of every NAL unit in one table; short units zero padded"""
+    cfg = streams.small_cfg()
+    nals = [gen.sps(cfg), gen.pps(cfg), gen.aud(0), b"\x09", b""] + \
+        [gen.slice_nal(cfg, streams.rich_slice(cfg, s, 2)) for s in range(5)]
+    data = streams.annexb([n for n in nals if n])
+    buf = np.frombuffer(data + b"\xff" * 64, dtype=np.uint8)
+    d_buf = engine.upload(buf)
+    tab, count, consumed, d_nals = engine.scan(d_buf, len(data), 64, keep=True)
+    for k in (1, 7, 16, 64, 256):
+        heads = engine.gather_nal_heads(d_buf, d_nals, count, k)
+        assert heads.shape == (count, k)
+        for i in range(count):
+            a, b = int(tab[i, 0]), int(tab[i, 1])
+            want = data[a:min(b, a + k)]
+            assert heads[i, :len(want)].tobytes() == want
+            assert not heads[i, len(want):].any()
+    import ctypes as C
+    from libh264_amd import capi
+    L = capi.engine_lib()
+    assert L.h264_amd_gather_nal_heads(engine.h, d_buf.ptr, d_nals.ptr, 3, 0,
+                                       d_buf.ptr) == -22
+    assert L.h264_amd_gather_nal_heads(engine.h, d_buf.ptr, d_nals.ptr, 3, 257,
+                                       d_buf.ptr) == -22
+    assert L.h264_amd_gather_nal_heads(engine.h, None, d_nals.ptr, 3, 8,
+                                       d_buf.ptr) == -22
+    assert L.h264_amd_gather_nal_heads(engine.h, d_buf.ptr, d_nals.ptr, 0, 8,
+                                       None) == 0
+
+
 def test_scan_cap_too_small(engine):
     data = b"".join(b"\x00\x00\x01\x09\x10" for _ in range(100))
     got, count, _ = gpu_nals(engine, data, cap=10)

@@ -20,7 +20,7 @@ sys.path.insert(0, os.path.join(ROOT, "tests"))
 HBM_PEAK_GBS = 8000.0
 
 
-def mixed_stream(target_bytes, threads):
+def mixed_stream(target_bytes, threads, seed0=0):
     """GOPs of SPS/PPS/AUD + one IDR and P slices of 1080p, 3- and 4-byte
     start codes, a filler now and then."""
     from libh264_amd import gen
@@ -31,7 +31,7 @@ def mixed_stream(target_bytes, threads):
                        idr=int(k % 8 == 0), nal_ref_idc=1, first_mb=0,
                        num_mbs=8160, frame_num=k % 16, density=5,
                        pm_i16x16=250, pm_skip=150, pm_intra_in_inter=200,
-                       pm_escape=5, seed=k + 1) for k in range(n)]
+                       pm_escape=5, seed=seed0 + k + 1) for k in range(n)]
     buf, offs, sizes = gen.batch(cfg, slices, threads=threads)
     sps, pps, aud, fil = gen.sps(cfg), gen.pps(cfg), gen.aud(0), gen.filler(40)
     parts = []
