@@ -427,6 +427,14 @@ def main():
                 "kernel_ms": round(k_ms, 3),
                 "algorithmic_bytes_read": total_bytes,
                 "algorithmic_bytes_written": out_bytes,
+                # a serial-dependency kernel is described by
+                # its waves in flight and what one wave gets done per cycle
+                "waves_in_flight": min(args.slices, 4096),
+                "waves_per_cu": min(args.slices, 4096) / 256.0,
+                "bits_per_wave_cycle": round(
+                    8.0 * total_bytes / args.slices /
+                    (k_ms * 1e-3 * 2.4e9 / max(1.0, args.slices / 4096.0)), 5),
+                "clock_ghz_assumed": 2.4,
                 "note": "CAVLC is a serial dependency chain per slice: the "
                         "kernel is latency bound, not HBM bound",
             },
