@@ -263,6 +263,18 @@ H264_API int h264_amd_scan(struct h264_amd_engine *eng,
 			   size_t *count,
 			   size_t *consumed);
 
+/* h264_byte_stream_to_avcc (ref src/h264.c:208-246) on a device buffer, in
+ * place: every four-byte start code 00 00 00 01 is replaced by the big-endian
+ * length of the NAL unit behind it (up to the next four-byte start code or the
+ * end of the buffer); three-byte start codes are payload, a start code in the
+ * buffer's last four bytes is left alone, bytes before the first start code
+ * are not touched -- exactly the reference's loop.  d_buf 16-byte aligned.
+ * Synchronous.  (The opposite direction is a chain of lengths, each found
+ * only through the one before: it stays on the host, h264_avcc_to_byte_stream.) */
+H264_API int h264_amd_byte_stream_to_avcc(struct h264_amd_engine *eng,
+					  uint8_t *d_buf,
+					  size_t len);
+
 /* Head bytes of every NAL unit of a scan, as one dense table: d_heads[i][j] =
  * d_buf[nal[i].start + j] for j < min(head_bytes, nal length), 0 beyond.  What
  * the host control plane of a device-resident pipeline needs to see -- the NAL
@@ -370,7 +382,8 @@ H264_API int h264_amd_cabac_init_states(struct h264_amd_engine *eng,
 
 /* Kernel timing: duration in ms of the most recent launch of the named
  * kernel family ("scan" = the marking kernel that reads the stream,
- * "scan_all" = marking + prefix + placement, "decode", "write", "synth"),
+ * "scan_all" = marking + prefix + placement, "decode", "write", "synth",
+ * "cabac", "avcc" = the whole byte-stream-to-AVCC conversion),
  * measured with HIP events on the engine stream.  Synchronises. */
 H264_API int h264_amd_last_kernel_ms(struct h264_amd_engine *eng,
 				     const char *family,

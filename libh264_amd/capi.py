@@ -56,6 +56,7 @@ def engine_lib():
     L.h264_amd_scan.argtypes = [vp, vp, sz, vp, sz, C.POINTER(sz),
                                 C.POINTER(sz)]
     L.h264_amd_gather_nal_heads.argtypes = [vp, vp, vp, sz, u32, vp]
+    L.h264_amd_byte_stream_to_avcc.argtypes = [vp, vp, sz]
     L.h264_amd_decode_slices.argtypes = [vp, vp, C.POINTER(DecodeArgs)]
     L.h264_amd_write_slices.argtypes = [vp, vp, C.POINTER(WriteArgs)]
     L.h264_amd_encode_synth_slices.argtypes = [vp, vp, C.POINTER(SynthArgs)]
@@ -187,6 +188,11 @@ class Engine:
         if keep:  # also hand back the device table (for gather_nal_heads)
             return tab.reshape(-1, 2), cnt.value, consumed.value, d_nals
         return tab.reshape(-1, 2), cnt.value, consumed.value
+
+    def byte_stream_to_avcc(self, d_buf, length):
+        """h264_byte_stream_to_avcc in place on a device buffer"""
+        _check(engine_lib().h264_amd_byte_stream_to_avcc(self.h, d_buf.ptr,
+                                                         length), "to_avcc")
 
     def gather_nal_heads(self, d_buf, d_nals, n, head_bytes=16):
         """[n, head_bytes] uint8: the first bytes of every NAL unit."""

@@ -61,7 +61,7 @@ static int hip_err(hipError_t e)
 		}                                                              \
 	} while (0)
 
-enum { FAM_SCAN, FAM_DECODE, FAM_WRITE, FAM_SYNTH, FAM_SCAN_ALL, FAM_CABAC, FAM_COUNT };
+enum { FAM_SCAN, FAM_DECODE, FAM_WRITE, FAM_SYNTH, FAM_SCAN_ALL, FAM_CABAC, FAM_AVCC, FAM_COUNT };
 
 /* Serial numbers are process-wide so that a params object allocated at the
  * address of a freed one can never look "unchanged" to an engine's cache. */
@@ -99,6 +99,8 @@ struct h264_amd_engine {
 	/* scan scratch */
 	scan_scratch scan;
 	uint32_t scan_seg_override; /* H264_AMD_SCAN_SEG (experiments, tests) */
+	struct h264_amd_nal *d_avcc_nals; /* h264_amd_byte_stream_to_avcc */
+	size_t cap_avcc_nals;
 };
 
 /* ---- lane tables from the standard's bit strings -------------------------- */
@@ -257,6 +259,7 @@ extern "C" int h264_amd_engine_destroy(struct h264_amd_engine *e)
 	hipFree(e->d_pps);
 	hipFree(e->d_epochs);
 	scan_scratch_free(&e->scan);
+	hipFree(e->d_avcc_nals);
 	if (e->own_stream)
 		hipStreamDestroy(e->stream);
 	delete e;
@@ -328,7 +331,8 @@ extern "C" int h264_amd_last_kernel_ms(struct h264_amd_engine *e,
 				       const char *family, float *ms)
 {
 	static const char *const names[FAM_COUNT] = {"scan", "decode", "write",
-						     "synth", "scan_all", "cabac"};
+						     "synth", "scan_all", "cabac",
+						     "avcc"};
 	if (e == NULL || family == NULL || ms == NULL)
 		return -EINVAL;
 	for (int f = 0; f < FAM_COUNT; f++) {

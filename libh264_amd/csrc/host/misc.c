@@ -175,6 +175,10 @@ int h264_avcc_to_byte_stream(uint8_t *data, size_t len)
 	if (data == NULL || len == 0)
 		return -EINVAL;
 	while (pos < len) {
+		/* deviation: the reference reads the four length bytes even when
+		 * fewer are left (src/h264.c:259-260) */
+		if (len - pos < 4)
+			return -EPROTO;
 		memcpy(&be, data + pos, 4);
 		nalu_len = ntohl(be);
 		if (nalu_len == 0)

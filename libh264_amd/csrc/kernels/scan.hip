@@ -120,7 +120,9 @@ struct scan_mark_args {
 
 /* wave-uniform walk state of one segment */
 struct scan_state {
-	uint32_t carry; /* bits 0-7: byte before the previous one, 8-15: previous */
+	/* the three bytes before the step: bits 0-7 third last, 8-15 second
+	 * last, 16-23 last */
+	uint32_t carry;
 	uint32_t opened; /* NALs opened in this segment */
 	uint64_t pending; /* payload start of the open NAL */
 	uint64_t first_e;
@@ -168,7 +170,12 @@ __device__ __forceinline__ void scan_emit(const scan_mark_args &a, uint32_t seg,
  * such a pair.  The step therefore first asks, in the 0x80-flag-per-byte
  * domain, whether ANY lane sees a zero pair (or the step inherits one): about
  * 30 vector instructions per 16 bytes.  Only then are the exact E / S masks
- * built and walked by the scalar state machine. */
+ * built and walked by the scalar state machine.
+ *
+ * AVCC: the variant for h264_byte_stream_to_avcc (ref src/h264.c:184-246):
+ * only the four-byte code 00 00 00 01 counts, it both ends the unit before it
+ * and starts the next one, whose payload begins four bytes later. */
+template <bool AVCC>
 __device__ __forceinline__ void scan_step(const scan_mark_args &a, scan_state &st,
 					  uint4 q, uint64_t cbase, uint32_t seg,
 					  uint32_t lane)
@@ -178,9 +185,11 @@ __device__ __forceinline__ void scan_step(const scan_mark_args &a, scan_state &s
 #pragma unroll
 	for (int k = 0; k < 4; k++)
 		z[k] = scan_zero_bytes(w[k]);
-	/* zero flags of the four bytes before this lane's 16 (bits 23, 31 used) */
-	const uint32_t zc = ((st.carry & 0xffu) == 0 ? 0x00800000u : 0u) |
-			    ((st.carry >> 8) == 0 ? 0x80000000u : 0u);
+	/* zero flags of the four bytes before this lane's 16 (bits 15, 23, 31
+	 * used) */
+	const uint32_t zc = ((st.carry & 0xffu) == 0 ? 0x00008000u : 0u) |
+			    (((st.carry >> 8) & 0xffu) == 0 ? 0x00800000u : 0u) |
+			    ((st.carry >> 16) == 0 ? 0x80000000u : 0u);
 	const uint32_t zb = scan_from_lane_below(z[3], zc, lane);
 	/* flag at byte j: bytes j - 1 and j are both zero */
 	uint32_t pair = z[0] & __builtin_amdgcn_alignbit(z[0], zb, 24);
@@ -188,22 +197,33 @@ __device__ __forceinline__ void scan_step(const scan_mark_args &a, scan_state &s
 	pair |= z[2] & __builtin_amdgcn_alignbit(z[2], z[1], 24);
 	pair |= z[3] & __builtin_amdgcn_alignbit(z[3], z[2], 24);
 	const uint32_t carry_in = st.carry;
-	/* next step's carry: last two bytes of lane 63 */
-	st.carry = (uint32_t)__builtin_amdgcn_readlane((int)(w[3] >> 16), 63);
-	if (__ballot(pair != 0) == 0 && carry_in != 0)
+	/* next step's carry: last three bytes of lane 63 */
+	st.carry = (uint32_t)__builtin_amdgcn_readlane((int)(w[3] >> 8), 63);
+	/* no zero pair in the step and none inherited: no code ends here */
+	if (__ballot(pair != 0) == 0 && (carry_in >> 8) != 0)
 		return;
 
 	uint32_t z16 = 0, le16 = 0;
 #pragma unroll
 	for (int k = 0; k < 4; k++) {
 		z16 |= scan_movemask(z[k]) << (4 * k);
-		le16 |= scan_movemask(scan_zero_bytes(w[k] & 0xfefefefeu)) << (4 * k);
+		/* byte <= 1; AVCC: byte == 1 */
+		le16 |= scan_movemask(scan_zero_bytes(
+				AVCC ? w[k] ^ 0x01010101u : w[k] & 0xfefefefeu))
+			<< (4 * k);
 	}
-	uint32_t zprev = ((zb >> 23) & 1u) | ((zb >> 30) & 2u);
-	uint32_t z18 = (z16 << 2) | zprev; /* bit j+2 = byte j */
-	/* code ENDING at byte j: bytes j-2, j-1 zero, byte j <= 1 */
-	uint32_t e16 = z18 & (z18 >> 1) & le16;
+	/* flags of the three bytes before the lane's own, then bit j+3 = byte j */
+	uint32_t zprev = ((zb >> 15) & 1u) | ((zb >> 22) & 2u) | ((zb >> 29) & 4u);
+	uint32_t z19 = (z16 << 3) | zprev;
+	/* code ENDING at byte j: bytes j-2, j-1 zero, byte j <= 1
+	 * (AVCC: bytes j-3, j-2, j-1 zero, byte j == 1) */
+	uint32_t e16 = (z19 >> 1) & (z19 >> 2) & le16;
 	uint32_t s16 = e16 & ~z16;
+	if (AVCC) {
+		e16 &= z19;
+		s16 = e16;
+	}
+	const uint32_t code_len = AVCC ? 4u : 3u;
 
 	unsigned long long em = __ballot(e16 != 0);
 	while (em) {
@@ -215,7 +235,7 @@ __device__ __forceinline__ void scan_step(const scan_mark_args &a, scan_state &s
 			uint32_t j = (uint32_t)__builtin_ctz(e);
 			e &= e - 1;
 			/* position of the code's first byte */
-			uint64_t p = cbase + 16u * (uint32_t)l + j - 2u;
+			uint64_t p = cbase + 16u * (uint32_t)l + j - (code_len - 1u);
 			if (st.first_e == SCAN_NONE)
 				st.first_e = p;
 			if (st.pending != SCAN_NONE) {
@@ -223,15 +243,15 @@ __device__ __forceinline__ void scan_step(const scan_mark_args &a, scan_state &s
 				st.pending = SCAN_NONE;
 			}
 			if ((s >> j) & 1u) {
-				st.pending = p + 3u;
+				st.pending = p + code_len;
 				st.opened++;
 			}
 		}
 	}
 }
 
-extern "C" __global__ void __launch_bounds__(64 * SCAN_WAVES_PER_BLOCK)
-h264_amd_k_scan_mark(scan_mark_args a)
+template <bool AVCC>
+__device__ __forceinline__ void scan_mark_body(const scan_mark_args &a)
 {
 	const uint32_t lane = threadIdx.x & 63u;
 	const uint32_t seg = (uint32_t)__builtin_amdgcn_readfirstlane(
@@ -255,10 +275,11 @@ h264_amd_k_scan_mark(scan_mark_args a)
 								16u * lane);
 	}
 	scan_state st;
-	/* the two bytes before the segment (0xff before the buffer) */
-	st.carry = 0xffffu;
-	if (lo >= 2)
-		st.carry = (uint32_t)a.buf[lo - 2] | ((uint32_t)a.buf[lo - 1] << 8);
+	/* the three bytes before the segment (0xff before the buffer) */
+	st.carry = 0xffffffu;
+	if (lo >= 3)
+		st.carry = (uint32_t)a.buf[lo - 3] | ((uint32_t)a.buf[lo - 2] << 8) |
+			   ((uint32_t)a.buf[lo - 1] << 16);
 	st.carry = (uint32_t)__builtin_amdgcn_readfirstlane((int)st.carry);
 	st.pending = SCAN_NONE;
 	st.first_e = SCAN_NONE;
@@ -274,7 +295,7 @@ h264_amd_k_scan_mark(scan_mark_args a)
 		}
 #pragma unroll
 		for (int u = 0; u < 4; u++)
-			scan_step(a, st, q[u], pos + 1024u * u, seg, lane);
+			scan_step<AVCC>(a, st, q[u], pos + 1024u * u, seg, lane);
 #pragma unroll
 		for (int u = 0; u < 4; u++)
 			q[u] = nq[u];
@@ -283,7 +304,7 @@ h264_amd_k_scan_mark(scan_mark_args a)
 		uint64_t off = cbase + 16u * lane;
 		uint4 t = off < hi ? scan_load16(a.buf, off, a.len)
 				   : make_uint4(~0u, ~0u, ~0u, ~0u);
-		scan_step(a, st, t, cbase, seg, lane);
+		scan_step<AVCC>(a, st, t, cbase, seg, lane);
 	}
 	if (st.pending != SCAN_NONE)
 		scan_emit(a, seg, st.opened - 1u, st.pending, SCAN_NONE, lane);
@@ -291,6 +312,40 @@ h264_amd_k_scan_mark(scan_mark_args a)
 		a.seg_count[seg] = st.opened;
 		a.seg_first_e[seg] = st.first_e;
 	}
+}
+
+extern "C" __global__ void __launch_bounds__(64 * SCAN_WAVES_PER_BLOCK)
+h264_amd_k_scan_mark(scan_mark_args a)
+{
+	scan_mark_body<false>(a);
+}
+
+/* four-byte start codes only (h264_byte_stream_to_avcc) */
+extern "C" __global__ void __launch_bounds__(64 * SCAN_WAVES_PER_BLOCK)
+h264_amd_k_scan_mark_avcc(scan_mark_args a)
+{
+	scan_mark_body<true>(a);
+}
+
+/* NAL unit lengths, big endian, over the four-byte start codes in front of the
+ * units of an AVCC-mode table (ref src/h264.c:232-241).  The reference leaves
+ * a start code at the very end of the buffer alone (its loop needs more than
+ * four bytes). */
+extern "C" __global__ void __launch_bounds__(256)
+h264_amd_k_avcc_lengths(uint8_t *buf, uint64_t len,
+			const struct h264_amd_nal *nals, uint64_t n)
+{
+	const uint64_t i = (uint64_t)blockIdx.x * 256u + threadIdx.x;
+	if (i >= n)
+		return;
+	const uint64_t s = nals[i].start, e = nals[i].end;
+	if (s < 4 || s >= len || e < s)
+		return;
+	const uint32_t v = (uint32_t)(e - s);
+	buf[s - 4] = (uint8_t)(v >> 24);
+	buf[s - 3] = (uint8_t)(v >> 16);
+	buf[s - 2] = (uint8_t)(v >> 8);
+	buf[s - 1] = (uint8_t)v;
 }
 
 /* Single block: exclusive scan of seg_count into seg_base, total into

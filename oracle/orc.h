@@ -295,6 +295,10 @@ int orc_parse_sps(const uint8_t *buf, size_t len, struct h264_sps *sps);
 int orc_parse_pps(const uint8_t *buf, size_t len, const struct h264_sps *sps,
 		  struct h264_pps *pps);
 
+/* AVCC <-> Annex-B byte stream, in place (orc_ctx.c; ref src/h264.c:184-272) */
+int orc_byte_stream_to_avcc(uint8_t *data, size_t len);
+int orc_avcc_to_byte_stream(uint8_t *data, size_t len);
+
 /* ---- CAVLC slice data (orc_cavlc.c; ref src/h264_syntax_slice_data.h,
  *      src/h264_slice_data.c, src/h264_macroblock.c) ------------------ */
 int orc_read_slice_data(struct h264_bitstream *bs, struct orc_reader *rd);

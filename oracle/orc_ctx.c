@@ -516,3 +516,65 @@ int orc_get_info_from_ps(const struct h264_sps *sps,
 	}
 	return 0;
 }
+
+/* ---- AVCC <-> byte stream (ref src/h264.c:184-272) --------------------- */
+static int find_start_code4(const uint8_t *buf, size_t len, size_t *start)
+{
+	const uint8_t *p = buf;
+	while (len >= 4) {
+		if (p[0] == 0 && p[1] == 0 && p[2] == 0 && p[3] == 1) {
+			*start = (size_t)(p - buf);
+			return 0;
+		}
+		p++;
+		len--;
+	}
+	return -ENOENT;
+}
+
+int orc_byte_stream_to_avcc(uint8_t *data, size_t len)
+{
+	size_t start, next_start, nalu_len;
+	if (data == NULL || len == 0)
+		return -EINVAL;
+	if (find_start_code4(data, len, &start) < 0)
+		return 0;
+	data += start;
+	len -= start;
+	while (len > 4) {
+		if (find_start_code4(data + 4, len - 4, &next_start) < 0)
+			nalu_len = len - 4;
+		else
+			nalu_len = next_start;
+		data[0] = (uint8_t)(nalu_len >> 24);
+		data[1] = (uint8_t)(nalu_len >> 16);
+		data[2] = (uint8_t)(nalu_len >> 8);
+		data[3] = (uint8_t)nalu_len;
+		data += 4 + nalu_len;
+		len -= 4 + nalu_len;
+	}
+	return 0;
+}
+
+int orc_avcc_to_byte_stream(uint8_t *data, size_t len)
+{
+	size_t offset = 0;
+	if (data == NULL || len == 0)
+		return -EINVAL;
+	while (offset < len) {
+		uint32_t nalu_len;
+		/* deviation shared with the product: the reference reads the four
+		 * length bytes even when fewer are left in the buffer */
+		if (len - offset < 4)
+			return -EPROTO;
+		nalu_len = ((uint32_t)data[offset] << 24) |
+			   ((uint32_t)data[offset + 1] << 16) |
+			   ((uint32_t)data[offset + 2] << 8) | data[offset + 3];
+		if (nalu_len == 0)
+			return -EPROTO;
+		data[offset] = data[offset + 1] = data[offset + 2] = 0;
+		data[offset + 3] = 1;
+		offset += 4 + (size_t)nalu_len;
+	}
+	return 0;
+}

@@ -264,3 +264,42 @@ def test_cabac_init_states(engine):
     for i, (st, idc, qp) in enumerate(triples):
         want = orc.cabac_init_states(st, idc, qp)
         assert np.array_equal(got[i], want), (st, idc, qp)
+
+
+def test_byte_stream_to_avcc(engine):
+    """h264_amd_byte_stream_to_avcc (the scan in four-byte-code mode + length
+    writer) against the oracle's restatement of the reference's loop, in
+    place: hand cases, byte soup, codes around step and segment edges, a real
+    stream, and a stream dense enough to need the second (exact) table pass."""
+    import ctypes as C
+    from test_host_control_plane import _avcc_cases
+    O = orc.lib()
+    O.orc_byte_stream_to_avcc.argtypes = [C.c_void_p, C.c_size_t]
+    cases = [c for c in _avcc_cases() if len(c) > 0]
+    rnd = random.Random(9)
+    for edge in (1024, 4096, 16384, 32768):
+        for shift in range(-6, 3):
+            d = bytearray(rnd.randrange(1, 256) for _ in range(edge + 2000))
+            d[3:7] = b"\x00\x00\x00\x01"
+            p = edge + shift
+            d[p:p + 5] = b"\x00\x00\x00\x00\x01"
+            d[p + 700:p + 703] = b"\x00\x00\x01"      # three bytes: payload
+            cases.append(bytes(d))
+    dense = bytearray(rnd.randrange(1, 256) for _ in range(120000))
+    for p in range(0, len(dense) - 8, 40):
+        dense[p:p + 4] = b"\x00\x00\x00\x01"
+    cases.append(bytes(dense))
+    big = bytearray(np.random.default_rng(5).integers(1, 256, size=5 << 20,
+                                                      dtype=np.uint8).tobytes())
+    for p in sorted(rnd.sample(range(0, len(big) - 8), 300)):
+        big[p:p + 4] = b"\x00\x00\x00\x01"
+    cases.append(bytes(big))
+    for data in cases:
+        want = C.create_string_buffer(data, len(data))
+        assert O.orc_byte_stream_to_avcc(want, len(data)) == 0
+        d_buf = engine.upload(np.frombuffer(data + b"\xff" * 64, dtype=np.uint8))
+        engine.byte_stream_to_avcc(d_buf, len(data))
+        got = engine.download(d_buf, len(data)).tobytes()
+        assert got == want.raw, (len(data), data[:12])
+        assert engine.download(d_buf, 64, offset=len(data)).tobytes() == \
+            b"\xff" * 64
