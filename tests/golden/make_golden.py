@@ -31,8 +31,8 @@ from h264types import Sps, Pps, SliceHeader  # noqa: E402
 from libh264_amd import gen  # noqa: E402
 
 
-def mixed(name, cfg, seed0, n_slices):
-    nals = streams.mixed_nals(cfg, n_slices=n_slices, seed0=seed0)
+def mixed(name, cfg, seed0, n_slices, **kw):
+    nals = streams.mixed_nals(cfg, n_slices=n_slices, seed0=seed0, **kw)
     rnd = random.Random(seed0)
     data = b"\x00\x00" + streams.annexb(
         nals, long_codes=[rnd.random() < 0.5 for _ in nals]) + b"\x00"
@@ -133,6 +133,13 @@ def main():
     print("mixed_422_10", mixed("mixed_422_10", streams.small_cfg(cf=2, bd=2),
                                 52, 8))
     print("mixed_444", mixed("mixed_444", streams.small_cfg(cf=3), 53, 8))
+    # interlaced material (frame / top / bottom field pictures, no MBAFF),
+    # pic_order_cnt_type 1, SP and SI slices beside I / P / B
+    print("mixed_interlaced", mixed(
+        "mixed_interlaced",
+        streams.small_cfg(field_coding=1, pic_order_cnt_type=1,
+                          bottom_field_pic_order_in_frame_present_flag=1),
+        60, 10, types=(2, 0, 1, 3, 4)))
     print("damaged_small", damaged("damaged_small", streams.small_cfg(), 9))
     synth("synth_grid")
     cabac("cabac_init")

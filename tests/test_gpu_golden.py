@@ -22,7 +22,8 @@ from libh264_amd.ctypes_abi import (Sps, Pps, SliceHeader, SliceResult,
 pytestmark = pytest.mark.gpu
 
 GOLDEN = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
-STREAMS = ["mixed_small", "mixed_400", "mixed_422_10", "mixed_444"]
+STREAMS = ["mixed_small", "mixed_400", "mixed_422_10", "mixed_444",
+           "mixed_interlaced"]
 EV_SPS, EV_PPS, EV_NALU_BEGIN, EV_PARSE_RESULT = 8, 9, 2, 13
 
 

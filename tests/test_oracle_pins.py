@@ -223,7 +223,7 @@ GOLDEN = os.path.join(orc.ROOT, "tests", "golden")
 
 
 @pytest.mark.parametrize("name", ["mixed_small", "mixed_400", "mixed_422_10",
-                                  "mixed_444"])
+                                  "mixed_444", "mixed_interlaced"])
 def test_oracle_reproduces_golden_streams(name):
     """tests/golden/*.npz were produced by tests/golden/make_golden.py; the
     oracle must keep producing them (regression pin across rounds)."""
