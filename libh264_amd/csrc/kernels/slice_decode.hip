@@ -920,6 +920,11 @@ sd_slice_data(WaveBits &wb, const VlcTabs &vt, uint32_t cbp_map, uint32_t lane,
 	const uint32_t skip_word0 =
 		(is_b ? (uint32_t)H264_MB_TYPE_B_SKIP : (uint32_t)H264_MB_TYPE_P_SKIP) |
 		(((uint32_t)H264_AMD_MB_SKIPPED | field_flag) << 16);
+	/* for coded macroblocks the flag waits in a vector register and joins
+	 * the record's first word there: a scalar carried through the whole
+	 * macroblock walk cost 0.7 % */
+	uint32_t v_field = field_flag << 16;
+	asm volatile("" : "+v"(v_field));
 
 	do {
 		wb_sync(wb, lane);
@@ -1031,7 +1036,7 @@ sd_slice_data(WaveBits &wb, const VlcTabs &vt, uint32_t cbp_map, uint32_t lane,
 			}
 		}
 
-		uint32_t flags = field_flag, icp = 0;
+		uint32_t flags = 0, icp = 0;
 		int32_t qpd = 0;
 		uint32_t pred_lo = 0, pred_hi = 0; /* pred[8] of the summary */
 
@@ -1311,7 +1316,7 @@ sd_slice_data(WaveBits &wb, const VlcTabs &vt, uint32_t cbp_map, uint32_t lane,
 					 (flags << 16) | ((raw_type & 0xffu) << 24);
 			uint32_t word1 = ((uint32_t)qpd & 0xffffu) |
 					 ((icp & 0xffu) << 16) | (i16pred << 24);
-			lds_w32(stage, 0, word0, lane);
+			lds_w32(stage, 0, word0 | v_field, lane);
 			lds_w32(stage, 4, word1, lane);
 			/* intra prediction modes are already in place */
 			if (pred_lo | pred_hi) {
