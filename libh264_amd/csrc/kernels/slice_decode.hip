@@ -234,6 +234,11 @@ sd_slice_header(WaveBits &wb, uint32_t lane, uint8_t *stage, SliceState &S,
 	RD_UE(pps_id);
 	HP(pic_parameter_set_id, pps_id);
 
+	/* a ue that ran past the end of the NAL is the reference's -EIO on the
+	 * read itself, before it looks at the value (found by the drop-in fuzz:
+	 * the zero padding made pps_id large and -EINVAL won) */
+	if (wb_overrun(wb))
+		return -EIO;
 	/* h264_ctx_set_active_pps -> set_active_sps (src/h264_ctx.c:366-386) */
 	if (pps_id >= 256)
 		return -EINVAL;

@@ -347,3 +347,24 @@ def test_pic_order_cnt_type_1(engine, always_zero, field_coding):
               for seed in range(8) for st in (2, 0, 1)]
     run_case(engine, cfg, slices, TIER_T2)
     __import__("test_gpu_scan_write").roundtrip_case(engine, cfg, slices)
+
+
+def test_pps_id_read_across_the_end_of_the_nal(engine):
+    """pic_parameter_set_id whose Exp-Golomb suffix is cut off by the end of
+    the NAL unit: -EIO from the read (as in the reference), not -EINVAL from
+    the value the zero padding produces.  Found by tools/fuzz_dropin.py."""
+    cfg = streams.small_cfg()
+    nals = [bytes.fromhex("210586000000da25"), bytes.fromhex("2105860000"),
+            bytes.fromhex("21058600000001"), bytes.fromhex("2588"),
+            bytes.fromhex("25")]
+    ref = orc.parse_nalus([gen.sps(cfg), gen.pps(cfg)] + nals)
+    assert ref.statuses[2] == -5
+    params = make_params(ref)
+    buf, offs, sizes = streams.pack_nals(nals)
+    d_buf = engine.upload(buf)
+    descs = [(o, s, params.epoch) for o, s in zip(offs, sizes)]
+    out = engine.decode_slices(params, d_buf, descs, reader_flags=1,
+                               tier=TIER_T2, mb_capacity=64, want_headers=True)
+    res = engine.fetch_results(out)
+    for i in range(len(nals)):
+        assert result_fields(res[i]) == result_fields(ref.results[i]), i
