@@ -1,0 +1,71 @@
+#!/usr/bin/env python3
+"""Turns two rocprofv3 --pmc passes over bench.py (FETCH_SIZE in one run,
+WRITE_SIZE in another: one counter per pass, as MI355X_MICROARCH.md's HBM
+section prescribes) into profiles/rNN_decode_hbm_traffic.json, the file
+bench.py reads `roofline.traffic` from.
+
+    cd /tmp && export TMPDIR=/tmp
+    rocprofv3 --kernel-trace --pmc FETCH_SIZE --output-format csv -d F -- \\
+        python3 bench.py --steps 2 --warmup 0 --verify 0 --cpu-sample 16
+    rocprofv3 --kernel-trace --pmc WRITE_SIZE --output-format csv -d W -- ...
+    python tools/pmc_traffic.py F W <bytes_per_gpu> <out.json>
+
+Units: rocprofv3 reports both counters in KiB; on gfx950 FETCH_SIZE counts a
+128-byte read request as 64 bytes (same guide): doubled here.
+"""
+import csv
+import glob
+import json
+import os
+import sys
+
+KERNEL = "h264_amd_k_decode_slices"
+
+
+def values(d, counter):
+    out = []
+    for f in glob.glob(os.path.join(d, "**", "*counter_collection.csv"),
+                       recursive=True):
+        for row in csv.DictReader(open(f)):
+            if row["Kernel_Name"].startswith(KERNEL) and \
+                    row["Counter_Name"] == counter:
+                out.append(float(row["Counter_Value"]))
+    return out
+
+
+def main():
+    fdir, wdir, nbytes, out = sys.argv[1], sys.argv[2], int(sys.argv[3]), \
+        sys.argv[4]
+    fetch, write = values(fdir, "FETCH_SIZE"), values(wdir, "WRITE_SIZE")
+    n = min(len(fetch), len(write))
+    if n == 0:
+        raise SystemExit("no %s dispatches found" % KERNEL)
+    rd = 2.0 * 1024.0 * sum(fetch[-n:]) / n
+    wr = 1024.0 * sum(write[-n:]) / n
+    algo_w = 4096 * (64 + 8160 * 4)
+    doc = {
+        "command": "rocprofv3 --kernel-trace --pmc <COUNTER> --output-format "
+                   "csv -- python3 bench.py --steps 2 --warmup 0 --verify 0 "
+                   "--cpu-sample 16  (one counter per pass), "
+                   "tools/pmc_traffic.py",
+        "kernel": KERNEL, "slices": 4096, "tier": "T0",
+        "bytes_per_gpu": nbytes,
+        "unit_note": "rocprofv3 reports FETCH_SIZE / WRITE_SIZE in KiB; on "
+                     "gfx950 FETCH_SIZE counts 128-B read requests as 64 B "
+                     "(MI355X_MICROARCH.md, HBM section): doubled",
+        "launches": [{"FETCH_SIZE_KiB": f, "WRITE_SIZE_KiB": w}
+                     for f, w in zip(fetch[-n:], write[-n:])],
+        "hbm_read_bytes_per_launch": int(rd),
+        "hbm_write_bytes_per_launch": int(wr),
+        "hbm_bytes_per_launch": int(rd + wr),
+        "algorithmic_read_bytes": nbytes,
+        "algorithmic_write_bytes": algo_w,
+        "read_over_algorithmic": round(rd / nbytes, 4),
+        "write_over_algorithmic": round(wr / algo_w, 4),
+    }
+    json.dump(doc, open(out, "w"), indent=1)
+    print(json.dumps(doc))
+
+
+if __name__ == "__main__":
+    main()
