@@ -586,7 +586,12 @@ extern "C" int h264_amd_decode_slices(struct h264_amd_engine *e,
 				      ? params->max_width_mbs
 				      : H264_AMD_MAX_PIC_WIDTH_MBS;
 
-	a.wave_lds_bytes = (SD_ROW_OFF + 16u * a.row_pitch + 255u) & ~255u;
+	{
+		uint32_t tail = SD_REC_BYTES + 16u * a.row_pitch;
+		if (tail < SD_STAGE_BYTES)
+			tail = SD_STAGE_BYTES;
+		a.wave_lds_bytes = (SD_STAGE_OFF + tail + 255u) & ~255u;
+	}
 	size_t lds = SD_TABS_BYTES + (size_t)SD_WAVES_PER_BLOCK * a.wave_lds_bytes;
 	if (lds > 160u * 1024u)
 		return -E2BIG;
@@ -594,10 +599,27 @@ extern "C" int h264_amd_decode_slices(struct h264_amd_engine *e,
 		HIP_TRY(hipFuncSetAttribute(
 			(const void *)h264_amd_k_decode_slices,
 			hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+	/* more than one round of 16 waves per CU: the 5-waves-per-SIMD build
+	 * (H264_AMD_DECODE_W5=0/1 forces one or the other) */
+	bool w5 = a.n > 4096u;
+	{
+		const char *v = getenv("H264_AMD_DECODE_W5");
+		if (v != NULL && (v[0] == '0' || v[0] == '1'))
+			w5 = v[0] == '1';
+	}
+	if (w5 && lds > 48u * 1024u)
+		HIP_TRY(hipFuncSetAttribute(
+			(const void *)h264_amd_k_decode_slices_w5,
+			hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
 	HIP_TRY(hipEventRecord(e->ev[FAM_DECODE][0], e->stream));
-	hipLaunchKernelGGL(h264_amd_k_decode_slices,
-			   dim3((a.n + SD_WAVES_PER_BLOCK - 1) / SD_WAVES_PER_BLOCK),
-			   dim3(64 * SD_WAVES_PER_BLOCK), lds, e->stream, a);
+	if (w5)
+		hipLaunchKernelGGL(h264_amd_k_decode_slices_w5,
+				   dim3((a.n + SD_WAVES_PER_BLOCK - 1) / SD_WAVES_PER_BLOCK),
+				   dim3(64 * SD_WAVES_PER_BLOCK), lds, e->stream, a);
+	else
+		hipLaunchKernelGGL(h264_amd_k_decode_slices,
+				   dim3((a.n + SD_WAVES_PER_BLOCK - 1) / SD_WAVES_PER_BLOCK),
+				   dim3(64 * SD_WAVES_PER_BLOCK), lds, e->stream, a);
 	HIP_TRY(hipGetLastError());
 	HIP_TRY(hipEventRecord(e->ev[FAM_DECODE][1], e->stream));
 	e->timed[FAM_DECODE] = true;

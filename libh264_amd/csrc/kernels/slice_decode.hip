@@ -56,8 +56,12 @@
 #define SD_STATE_OFF 1024u
 #define SD_DUMP_OFF (1024u + WB_STATE_BYTES)
 #define SD_STAGE_OFF (SD_DUMP_OFF + 1024u) /* dump area right before stage */
-#define SD_STAGE_BYTES 4096u
-#define SD_ROW_OFF (SD_STAGE_OFF + SD_STAGE_BYTES)
+#define SD_STAGE_BYTES 4096u /* the slice header image (3968 B) is built here */
+/* the macroblock record staged during slice data needs 1792 bytes at most, and
+ * the header image has left for HBM by then: the row context starts inside the
+ * staging area's second half (20 instead of 16 waves per CU fit at 1080p) */
+#define SD_REC_BYTES 2048u
+#define SD_ROW_OFF (SD_STAGE_OFF + SD_REC_BYTES)
 
 /* private enums of the reference (src/h264_macroblock.h:36-60) */
 enum { PM_I4x4, PM_I8x8, PM_I16x16, PM_L0, PM_L1, PM_BI, PM_DIRECT };
@@ -1355,11 +1359,12 @@ struct sd_args {
 	struct h264_slice_header *headers;
 	uint8_t *mb_out;
 	uint32_t row_pitch; /* macroblock columns of row context in LDS */
-	uint32_t wave_lds_bytes; /* LDS of one wave: SD_ROW_OFF + 16 * row_pitch */
+	/* LDS of one wave: SD_STAGE_OFF + max(SD_STAGE_BYTES, SD_REC_BYTES + 16 *
+	 * row_pitch) */
+	uint32_t wave_lds_bytes;
 };
 
-extern "C" __global__ void __launch_bounds__(64 * SD_WAVES_PER_BLOCK, 4)
-h264_amd_k_decode_slices(sd_args a)
+__device__ __forceinline__ void sd_kernel_body(const sd_args &a)
 {
 	extern __shared__ __attribute__((aligned(16))) uint8_t lds_all[];
 	vlc_stage_tables(lds_all, a.vlc, threadIdx.x, 64u * SD_WAVES_PER_BLOCK);
@@ -1532,3 +1537,18 @@ h264_amd_k_decode_slices(sd_args a)
 	}
 }
 
+/* 128 registers, 4 waves per SIMD: the fastest wave; batches that fill the
+ * chip once (up to 4096 slices) */
+extern "C" __global__ void __launch_bounds__(64 * SD_WAVES_PER_BLOCK, 4)
+h264_amd_k_decode_slices(sd_args a)
+{
+	sd_kernel_body(a);
+}
+
+/* 96 registers, 5 waves per SIMD: more waves to hide one another's latency,
+ * for batches of more than one round */
+extern "C" __global__ void __launch_bounds__(64 * SD_WAVES_PER_BLOCK, 5)
+h264_amd_k_decode_slices_w5(sd_args a)
+{
+	sd_kernel_body(a);
+}
