@@ -293,3 +293,29 @@ def test_avcc_against_the_oracle():
         assert H.h264_avcc_to_byte_stream(a, len(bad)) == want
         assert O.orc_avcc_to_byte_stream(b, len(bad)) == want
         assert a.raw == b.raw
+
+
+def test_avcc_random_buffers_against_the_oracle():
+    """2000 random buffers rich in start-code fragments through both
+    directions, product host code vs oracle, in place"""
+    import random
+    import orc
+    H = prod.h264()
+    O = orc.lib()
+    for f in (H.h264_byte_stream_to_avcc, H.h264_avcc_to_byte_stream,
+              O.orc_byte_stream_to_avcc, O.orc_avcc_to_byte_stream):
+        f.argtypes = [C.c_void_p, C.c_size_t]
+    rnd = random.Random(77)
+    frags = [b"\x00\x00\x00\x01", b"\x00\x00\x01", b"\x00", b"\x00\x00",
+             b"\x00\x00\x00", b"\x01", b"\x65\x88", b"\xff", b"\x00\x00\x00\x02"]
+    for _ in range(2000):
+        data = b"".join(rnd.choice(frags) if rnd.random() < 0.6 else
+                        bytes(rnd.randrange(256) for _ in range(rnd.randrange(1, 9)))
+                        for _ in range(rnd.randrange(1, 30)))
+        for fh, fo in ((H.h264_byte_stream_to_avcc, O.orc_byte_stream_to_avcc),
+                       (H.h264_avcc_to_byte_stream, O.orc_avcc_to_byte_stream)):
+            a = C.create_string_buffer(data, len(data) + 8)
+            b = C.create_string_buffer(data, len(data) + 8)
+            assert fh(a, len(data)) == fo(b, len(data)), data.hex()
+            assert a.raw == b.raw, data.hex()
+            assert a.raw[len(data):] == b"\x00" * 8  # nothing past the end
