@@ -173,6 +173,12 @@ int orc_new_macroblock(struct orc_ctx *ctx, uint32_t mbAddr, int skipped,
 	uint32_t off = mb_off(ctx, mbAddr);
 	struct orc_mb *mb;
 
+	/* an MBAFF frame slice with first_mb_in_slice > 0 reaches here through the
+	 * synthetic-slice writers with mbAddr below first_mb_in_slice * 2: the
+	 * offset wraps and the reference asks realloc for ~200 GB, which fails
+	 * on one machine and grinds for minutes on another.  Here: -ENOMEM. */
+	if (off >= H264_AMD_MAX_SLICE_MBS)
+		return -ENOMEM;
 	if ((size_t)off + 1 > ctx->slice.mb_table.maxlen) {
 		size_t nl = ((size_t)off + 1 + 127) & ~(size_t)127;
 		struct orc_mb_info *ni = realloc(ctx->slice.mb_table.info,
