@@ -34,8 +34,7 @@
 
 #define CB_RING_OFF 0u
 #define CB_STATE_OFF 1024u
-#define CB_DUMP_OFF (1024u + WB_STATE_BYTES)
-#define CB_STAGE_OFF (CB_DUMP_OFF + SD_DUMP_BYTES) /* dump right before stage */
+#define CB_STAGE_OFF (1024u + WB_STATE_BYTES)
 #define CB_STAGE_BYTES 2048u /* largest T2 record: 1792 B */
 #define CB_CTX_OFF (CB_STAGE_OFF + CB_STAGE_BYTES)
 #define CB_ROW_OFF (CB_CTX_OFF + 2048u)
