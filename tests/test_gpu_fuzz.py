@@ -48,19 +48,27 @@ def mutate(nal, rnd):
 
 
 @pytest.mark.parametrize("cf,bd,seed", [(1, 0, 1), (1, 0, 2), (0, 0, 3),
-                                        (2, 2, 4), (3, 0, 5), (1, 0, 6)])
+                                        (2, 2, 4), (3, 0, 5), (1, 0, 6),
+                                        (1, 0, 7), (2, 0, 8)])
 def test_damaged_slices_at_volume(engine, cf, bd, seed):
     rnd = random.Random(seed)
-    cfg = streams.small_cfg(cf=cf, bd=bd)
+    # seeds 7 and 8: interlaced material with pic_order_cnt_type 1, SP and SI
+    # slices among the types
+    extra = dict(field_coding=1, pic_order_cnt_type=1,
+                 bottom_field_pic_order_in_frame_present_flag=1) \
+        if seed >= 7 else {}
+    types = (2, 0, 1, 7, 5, 6, 3, 4) if seed >= 7 else (2, 0, 1, 7, 5, 6)
+    cfg = streams.small_cfg(cf=cf, bd=bd, **extra)
     total = cfg.width_mbs * cfg.height_mbs
     nals = []
     for k in range(240):
-        st = (2, 0, 1, 7, 5, 6)[k % 6]
+        st = types[k % len(types)]
         first = rnd.choice([0, 0, 0, rnd.randrange(total - 1)])
         n = rnd.randrange(1, total - first + 1) if first else total
         s = streams.rich_slice(cfg, seed * 1000 + k, st, first, n,
                                density=rnd.randrange(0, 15),
-                               pm_escape=rnd.choice([0, 20, 300]))
+                               pm_escape=rnd.choice([0, 20, 300]),
+                               field_pic=k % 3 if extra else 0)
         nal = gen.slice_nal(cfg, s)
         nals.append(mutate(nal, rnd) if k % 8 else nal)  # every 8th intact
     ref = orc.parse_nalus([gen.sps(cfg), gen.pps(cfg)] + nals)
