@@ -79,7 +79,8 @@ def test_ipb_slices_420(engine, tier):
     run_case(engine, cfg, slices, tier)
 
 
-@pytest.mark.parametrize("cf,bd", [(0, 0), (2, 0), (3, 0), (1, 2), (3, 4)])
+@pytest.mark.parametrize("cf,bd", [(0, 0), (2, 0), (3, 0), (1, 2), (3, 4),
+                                   (1, 6), (3, 6), (0, 5)])
 def test_chroma_formats(engine, cf, bd):
     cfg = streams.small_cfg(cf=cf, bd=bd, weighted_pred_flag=1,
                             weighted_bipred_idc=1,

@@ -37,7 +37,7 @@ def roundtrip(cfg, slices):
 
 
 @pytest.mark.parametrize("cf,bd", [(1, 0), (0, 0), (2, 0), (2, 2), (3, 0),
-                                   (3, 4)])
+                                   (3, 4), (1, 6), (3, 6), (0, 5)])
 def test_all_chroma_formats(cf, bd):
     cfg = streams.small_cfg(cf=cf, bd=bd)
     slices = [streams.rich_slice(cfg, seed, (2, 0, 1)[seed % 3])
