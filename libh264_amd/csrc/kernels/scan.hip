@@ -119,6 +119,9 @@ struct scan_mark_args {
 };
 
 /* wave-uniform walk state of one segment */
+#define SCAN_OVF_BATCH 64u /* overflow records a wave collects before it takes
+			     * list slots for all of them with ONE atomic */
+
 struct scan_state {
 	/* the three bytes before the step: bits 0-7 third last, 8-15 second
 	 * last, 16-23 last */
@@ -126,6 +129,7 @@ struct scan_state {
 	uint32_t opened; /* NALs opened in this segment */
 	uint64_t pending; /* payload start of the open NAL */
 	uint64_t first_e;
+	uint32_t ovf; /* overflow records waiting in the wave's LDS batch */
 };
 
 /* value of the lane below (lane 0: `first`): one DPP move, no LDS crossbar */
@@ -137,30 +141,50 @@ __device__ __forceinline__ uint32_t scan_from_lane_below(uint32_t v, uint32_t fi
 	return lane == 0 ? first : up;
 }
 
+/* the wave's batch of overflow records goes to the list: one atomic for all
+ * of them (a single counter taken once per record serialises at ~9 ns per
+ * NAL unit), lane k stores record k */
+__device__ __forceinline__ void scan_flush(const scan_mark_args &a, scan_state &st,
+					   const scan_rec *batch, uint32_t lane)
+{
+	if (st.ovf == 0)
+		return;
+	uint32_t base = 0;
+	if (lane == 0)
+		base = atomicAdd(&a.counter[0], st.ovf);
+	base = (uint32_t)__builtin_amdgcn_readfirstlane((int)base);
+	if (lane < st.ovf && base + lane < a.cap_recs && base + lane >= base)
+		a.recs[base + lane] = batch[lane];
+	st.ovf = 0;
+}
+
 /* NAL number `local` of segment `seg` is complete (or, end == SCAN_NONE, still
  * open where the segment ends) */
-__device__ __forceinline__ void scan_emit(const scan_mark_args &a, uint32_t seg,
+__device__ __forceinline__ void scan_emit(const scan_mark_args &a, scan_state &st,
+					  scan_rec *batch, uint32_t seg,
 					  uint32_t local, uint64_t start,
 					  uint64_t end, uint32_t lane)
 {
-	if (lane != 0)
-		return;
 	if (local < a.inline_per_seg) {
-		scan_inline_rec r;
-		r.start = start;
-		r.end = end;
-		a.inl[(size_t)seg * a.inline_per_seg + local] = r;
+		if (lane == 0) {
+			scan_inline_rec r;
+			r.start = start;
+			r.end = end;
+			a.inl[(size_t)seg * a.inline_per_seg + local] = r;
+		}
 		return;
 	}
-	uint32_t slot = atomicAdd(&a.counter[0], 1u);
-	if (slot < a.cap_recs) {
+	if (lane == 0) {
 		scan_rec r;
 		r.start = start;
 		r.end = end;
 		r.seg = seg;
 		r.local = local;
-		a.recs[slot] = r;
+		batch[st.ovf] = r;
 	}
+	st.ovf++;
+	if (st.ovf == SCAN_OVF_BATCH)
+		scan_flush(a, st, batch, lane);
 }
 
 /* One 1 KiB step: lane l holds bytes cbase + 16 l .. + 15 in q.
@@ -177,8 +201,8 @@ __device__ __forceinline__ void scan_emit(const scan_mark_args &a, uint32_t seg,
  * and starts the next one, whose payload begins four bytes later. */
 template <bool AVCC>
 __device__ __forceinline__ void scan_step(const scan_mark_args &a, scan_state &st,
-					  uint4 q, uint64_t cbase, uint32_t seg,
-					  uint32_t lane)
+					  scan_rec *batch, uint4 q, uint64_t cbase,
+					  uint32_t seg, uint32_t lane)
 {
 	const uint32_t w[4] = {q.x, q.y, q.z, q.w};
 	uint32_t z[4];
@@ -239,7 +263,8 @@ __device__ __forceinline__ void scan_step(const scan_mark_args &a, scan_state &s
 			if (st.first_e == SCAN_NONE)
 				st.first_e = p;
 			if (st.pending != SCAN_NONE) {
-				scan_emit(a, seg, st.opened - 1u, st.pending, p, lane);
+				scan_emit(a, st, batch, seg, st.opened - 1u, st.pending, p,
+					  lane);
 				st.pending = SCAN_NONE;
 			}
 			if ((s >> j) & 1u) {
@@ -253,6 +278,8 @@ __device__ __forceinline__ void scan_step(const scan_mark_args &a, scan_state &s
 template <bool AVCC>
 __device__ __forceinline__ void scan_mark_body(const scan_mark_args &a)
 {
+	__shared__ scan_rec s_batch[SCAN_WAVES_PER_BLOCK][SCAN_OVF_BATCH];
+	scan_rec *batch = s_batch[threadIdx.x >> 6];
 	const uint32_t lane = threadIdx.x & 63u;
 	const uint32_t seg = (uint32_t)__builtin_amdgcn_readfirstlane(
 		(int)(blockIdx.x * SCAN_WAVES_PER_BLOCK + (threadIdx.x >> 6)));
@@ -284,6 +311,7 @@ __device__ __forceinline__ void scan_mark_body(const scan_mark_args &a)
 	st.pending = SCAN_NONE;
 	st.first_e = SCAN_NONE;
 	st.opened = 0;
+	st.ovf = 0;
 
 	for (uint64_t pos = lo; pos < full_hi; pos += SCAN_BLOCK_BYTES) {
 		const uint64_t nx = pos + SCAN_BLOCK_BYTES;
@@ -295,7 +323,7 @@ __device__ __forceinline__ void scan_mark_body(const scan_mark_args &a)
 		}
 #pragma unroll
 		for (int u = 0; u < 4; u++)
-			scan_step<AVCC>(a, st, q[u], pos + 1024u * u, seg, lane);
+			scan_step<AVCC>(a, st, batch, q[u], pos + 1024u * u, seg, lane);
 #pragma unroll
 		for (int u = 0; u < 4; u++)
 			q[u] = nq[u];
@@ -304,10 +332,12 @@ __device__ __forceinline__ void scan_mark_body(const scan_mark_args &a)
 		uint64_t off = cbase + 16u * lane;
 		uint4 t = off < hi ? scan_load16(a.buf, off, a.len)
 				   : make_uint4(~0u, ~0u, ~0u, ~0u);
-		scan_step<AVCC>(a, st, t, cbase, seg, lane);
+		scan_step<AVCC>(a, st, batch, t, cbase, seg, lane);
 	}
 	if (st.pending != SCAN_NONE)
-		scan_emit(a, seg, st.opened - 1u, st.pending, SCAN_NONE, lane);
+		scan_emit(a, st, batch, seg, st.opened - 1u, st.pending, SCAN_NONE,
+			  lane);
+	scan_flush(a, st, batch, lane);
 	if (lane == 0) {
 		a.seg_count[seg] = st.opened;
 		a.seg_first_e[seg] = st.first_e;
