@@ -62,6 +62,28 @@ __global__ void __launch_bounds__(256) k_interleave(const u32x4 *p, size_t n16, 
 	if (acc == 0x12345678u) out[0] = acc;
 }
 
+// D: plain copy, 16 B per lane, each wave its own contiguous segment (what the
+// slice write-back does per slice) / grid-stride
+__global__ void __launch_bounds__(256) k_copy_segment(const u32x4 *p, u32x4 *q, size_t n16, uint32_t seg16)
+{
+	size_t wave = (size_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+	uint32_t lane = threadIdx.x & 63;
+	size_t lo = wave * seg16, hi = lo + seg16;
+	if (hi > n16) hi = n16;
+	for (size_t i = lo; i + 256 <= hi; i += 256) {
+		u32x4 a = p[i + lane], b = p[i + 64 + lane], c = p[i + 128 + lane], d = p[i + 192 + lane];
+		q[i + lane] = a; q[i + 64 + lane] = b; q[i + 128 + lane] = c; q[i + 192 + lane] = d;
+	}
+}
+__global__ void __launch_bounds__(256) k_copy_gridstride(const u32x4 *p, u32x4 *q, size_t n16)
+{
+	size_t i = (size_t)blockIdx.x * 256 + threadIdx.x, stride = (size_t)gridDim.x * 256;
+	for (; i + 3 * stride < n16; i += 4 * stride) {
+		u32x4 a = p[i], b = p[i + stride], c = p[i + 2 * stride], d = p[i + 3 * stride];
+		q[i] = a; q[i + stride] = b; q[i + 2 * stride] = c; q[i + 3 * stride] = d;
+	}
+}
+
 template <typename F> static double timeit(F f, int reps = 10)
 {
 	hipEvent_t e0, e1; CHECK(hipEventCreate(&e0)); CHECK(hipEventCreate(&e1));
@@ -91,5 +113,18 @@ int main(int argc, char **argv)
 	}
 	for (int blocks : {1024, 2048, 4096})
 		rep(("interleave b" + std::to_string(blocks)).c_str(), timeit([&] { k_interleave<<<blocks, 256>>>(d, n16, out); }));
+	{
+		u32x4 *q; CHECK(hipMalloc(&q, bytes));
+		auto rep2 = [&](const char *name, double ms) {
+			printf("{\"probe\": \"%s\", \"mib\": %zu, \"ms\": %.4f, \"GBps_read_plus_write\": %.1f}\n", name, mib, ms, 2.0 * bytes / ms / 1e6);
+			fflush(stdout);
+		};
+		for (uint32_t seg : {16384u, 163840u}) {
+			uint32_t seg16 = seg / 16; size_t waves = (n16 + seg16 - 1) / seg16;
+			rep2(("copy segment " + std::to_string(seg)).c_str(), timeit([&] { k_copy_segment<<<(waves + 3) / 4, 256>>>(d, q, n16, seg16); }));
+		}
+		for (int blocks : {2048, 8192})
+			rep2(("copy gridstride b" + std::to_string(blocks)).c_str(), timeit([&] { k_copy_gridstride<<<blocks, 256>>>(d, q, n16); }));
+	}
 	return 0;
 }
