@@ -127,6 +127,7 @@ static inline uint32_t h264_amd_t2_stride(uint32_t chroma_array_type)
 /* Engine-specific status values besides negative errno */
 #define H264_AMD_E_UNSUPPORTED (-ENOSYS) /* MBAFF / FMO; CABAC beyond the subset; absurd widths */
 #define H264_AMD_E_MB_OVERFLOW (-EOVERFLOW) /* more MBs than mb_capacity */
+#define H264_AMD_E_BAD_DESC (-EFAULT) /* descriptor outside d_buf_len */
 /* Most macroblocks one slice may deliver (64 pictures of 4096 x 2304): where the
  * drop-in reader stops growing a slice's record area, and where the oracle
  * stops too.  Only a damaged mb_skip_run gets anywhere near. */
@@ -311,6 +312,11 @@ struct h264_amd_decode_args {
 	uint8_t *d_mb_out; /* n * mb_capacity * mb_stride bytes, or NULL */
 	uint32_t mb_stride; /* bytes per MB record for the tier */
 	uint32_t reserved;
+	/* size of the allocation behind d_buf, or 0 if the caller vouches for its
+	 * descriptors.  When given, a descriptor reaching past it costs that slice
+	 * H264_AMD_E_BAD_DESC instead of a faulting kernel (a GPU memory fault
+	 * can take down more than the process). */
+	uint64_t d_buf_len;
 };
 H264_API int h264_amd_decode_slices(struct h264_amd_engine *eng,
 				    const struct h264_amd_params *params,
@@ -334,6 +340,7 @@ struct h264_amd_write_args {
 	 * a NAL ends inside a byte (no slice data given) the pending bits are
 	 * stored, left aligned, in the byte following the last whole one. */
 	uint32_t *d_out_hdr_bits;
+	uint64_t d_src_len; /* as d_buf_len of h264_amd_decode_args */
 };
 /* wflags: bits 0-1 = number of zero bytes (0..2) that precede the output in
  * the caller's bitstream (they take part in the 00 00 0x escape rule),

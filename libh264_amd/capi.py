@@ -240,6 +240,7 @@ class Engine:
         a.d_headers = out["headers"].ptr if want_headers else None
         a.d_mb_out = out["mb"].ptr if tier != TIER_NONE else None
         a.mb_stride = stride
+        a.d_buf_len = d_buf.nbytes  # descriptors are checked against it
         _check(engine_lib().h264_amd_decode_slices(self.h, params.h,
                                                    C.byref(a)), "decode")
         out["stride"] = stride
@@ -270,6 +271,7 @@ class Engine:
         a.d_out_offsets = d_offs.ptr
         a.d_out_sizes = d_sizes.ptr
         a.out_capacity = cap
+        a.d_src_len = d_src.nbytes
         _check(engine_lib().h264_amd_write_slices(self.h, params.h,
                                                   C.byref(a)), "write")
         if sync:

@@ -577,6 +577,7 @@ extern "C" int h264_amd_decode_slices(struct h264_amd_engine *e,
 	a.results = args->d_results;
 	a.headers = args->d_headers;
 	a.mb_out = args->d_mb_out;
+	a.buf_len = args->d_buf_len;
 	/* row context only where slice data is walked, and never for more
 	 * columns than H264_AMD_MAX_PIC_WIDTH_MBS: one damaged SPS must not make
 	 * the whole batch unlaunchable (it used to: -E2BIG for every slice) */

@@ -1358,6 +1358,7 @@ struct sd_args {
 	struct h264_amd_slice_result *results;
 	struct h264_slice_header *headers;
 	uint8_t *mb_out;
+	uint64_t buf_len; /* bytes behind buf, 0 = not checked */
 	uint32_t row_pitch; /* macroblock columns of row context in LDS */
 	/* LDS of one wave: SD_STAGE_OFF + max(SD_STAGE_BYTES, SD_REC_BYTES + 16 *
 	 * row_pitch) */
@@ -1382,8 +1383,11 @@ __device__ __forceinline__ void sd_kernel_body(const sd_args &a)
 
 	struct h264_amd_slice_desc d;
 	sd_load_uniform(&d, a.descs + slice);
-	const uint32_t len = d.size;
-	const uint8_t *nal = a.buf + d.offset;
+	/* a descriptor reaching past the buffer is answered, not followed */
+	const bool bad_desc = a.buf_len != 0 &&
+			      (d.offset > a.buf_len || d.size > a.buf_len - d.offset);
+	const uint32_t len = bad_desc ? 0u : d.size;
+	const uint8_t *nal = a.buf + (bad_desc ? 0u : d.offset);
 
 	SliceState S;
 	S.cat = 1;
@@ -1421,7 +1425,7 @@ __device__ __forceinline__ void sd_kernel_body(const sd_args &a)
 
 	/* NAL unit header (ref src/h264_syntax.h:1434-1443) */
 	if (len == 0) {
-		status = -EIO;
+		status = bad_desc ? H264_AMD_E_BAD_DESC : -EIO;
 	} else {
 		uint32_t h = wb_u(wb, lane, 8);
 		if (h & 0x80u)

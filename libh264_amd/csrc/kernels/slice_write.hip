@@ -473,6 +473,7 @@ struct sw_args {
 	uint32_t out_capacity;
 	uint32_t wflags;
 	uint32_t *out_hdr_bits;
+	uint64_t src_len; /* bytes behind src, 0 = not checked */
 };
 
 #define SW_HDR_OFF 0u
@@ -575,8 +576,12 @@ h264_amd_k_write_slices(sw_args a)
 			total = w.pos;
 		} else if (status == 0) {
 			bw_drain(w, lane);
-			if (w.overflow || w.pos + res.rawdata_len > a.out_capacity ||
-			    res.rawdata_off + res.rawdata_len > d.size) {
+			if (a.src_len != 0 &&
+			    (d.offset > a.src_len || d.size > a.src_len - d.offset)) {
+				status = H264_AMD_E_BAD_DESC;
+			} else if (w.overflow ||
+				   w.pos + res.rawdata_len > a.out_capacity ||
+				   res.rawdata_off + res.rawdata_len > d.size) {
 				status = -EIO;
 			} else {
 				sw_copy(dst + w.pos, a.src + d.offset + res.rawdata_off,

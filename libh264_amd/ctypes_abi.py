@@ -291,7 +291,7 @@ class DecodeArgs(S):
                 ("reader_flags", u32), ("tier", u32), ("mb_capacity", u32),
                 ("d_results", C.c_void_p), ("d_headers", C.c_void_p),
                 ("d_mb_out", C.c_void_p), ("mb_stride", u32),
-                ("reserved", u32)]
+                ("reserved", u32), ("d_buf_len", u64)]
 
 
 class WriteArgs(S):
@@ -300,7 +300,7 @@ class WriteArgs(S):
                 ("n", u32), ("wflags", u32), ("d_out", C.c_void_p),
                 ("d_out_offsets", C.c_void_p), ("d_out_sizes", C.c_void_p),
                 ("out_capacity", u32), ("reserved2", u32),
-                ("d_out_hdr_bits", C.c_void_p)]
+                ("d_out_hdr_bits", C.c_void_p), ("d_src_len", u64)]
 
 
 class SynthDesc(S):

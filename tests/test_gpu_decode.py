@@ -369,3 +369,33 @@ def test_pps_id_read_across_the_end_of_the_nal(engine):
     res = engine.fetch_results(out)
     for i in range(len(nals)):
         assert result_fields(res[i]) == result_fields(ref.results[i]), i
+
+
+def test_descriptors_outside_the_buffer_are_answered_not_followed(engine):
+    """with d_buf_len / d_src_len given, a descriptor that reaches past the
+    buffer costs its slice H264_AMD_E_BAD_DESC (-EFAULT); the kernels never
+    dereference it (a GPU memory fault can take the whole host's GPUs down)"""
+    cfg = streams.small_cfg()
+    nals = [gen.slice_nal(cfg, streams.rich_slice(cfg, s, 2)) for s in range(3)]
+    ref = orc.parse_nalus([gen.sps(cfg), gen.pps(cfg)] + nals)
+    params = make_params(ref)
+    buf, offs, sizes = streams.pack_nals(nals)
+    d_buf = engine.upload(buf)
+    n = d_buf.nbytes
+    descs = [(offs[0], sizes[0], params.epoch),
+             (n + 4096, 100, params.epoch),           # starts behind the end
+             (offs[1], n, params.epoch),              # runs past the end
+             ((1 << 64) - 8, 64, params.epoch),       # offset + size wraps
+             (n - 4, 8, params.epoch),                # straddles the end
+             (offs[2], sizes[2], params.epoch)]
+    out = engine.decode_slices(params, d_buf, descs, reader_flags=1,
+                               tier=TIER_T2, mb_capacity=64, want_headers=True)
+    res = engine.fetch_results(out)
+    assert [r.status for r in res] == [0, -14, -14, -14, -14, 0]
+    assert [r.mb_count for r in res] == [48, 0, 0, 0, 0, 48]
+    for i, k in ((0, 0), (5, 2)):
+        assert result_fields(res[i]) == result_fields(ref.results[k])
+    d_out, ooffs, osizes = engine.write_slices(params, d_buf, out,
+                                               max(sizes) + 64)
+    assert int(osizes[0]) == sizes[0] and int(osizes[5]) == sizes[2]
+    assert all(int(osizes[i]) < 0 for i in (1, 2, 3, 4))
