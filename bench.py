@@ -351,6 +351,17 @@ def main():
                 C.byref(mbs), C.byref(byts))
             if rc != 0 or mbs.value != 8160 * n_s:
                 raise SystemExit("cpu baseline failed: rc %d" % rc)
+            # one thread on a smaller sample of the same slices (BASELINE.md 3:
+            # single-thread and all-cores numbers side by side)
+            n_1 = min(n_s, 96)
+            s1, m1, b1 = C.c_double(), C.c_uint64(), C.c_uint64()
+            rc = orc.lib().orc_bench_slices(
+                buf.ctypes.data_as(C.c_void_p), o.ctypes.data_as(C.c_void_p),
+                z.ctypes.data_as(C.c_void_p), n_1, sps_nal, len(sps_nal),
+                pps_nal, len(pps_nal), 1, 1, C.byref(s1), C.byref(m1),
+                C.byref(b1))
+            if rc != 0 or m1.value != 8160 * n_1:
+                raise SystemExit("cpu baseline (1 thread) failed: rc %d" % rc)
             cpu = {
                 "value": round(8.0 * byts.value / secs.value / 1e6, 1),
                 "unit": "Mbit/s",
@@ -360,6 +371,10 @@ def main():
                 "sample": "%d of the same 1080p I-slices (%.1f MB), oracle "
                           "reader with slice_data, one reader per thread, "
                           "%.1f s wall" % (n_s, byts.value / 1e6, secs.value),
+                "single_thread": {
+                    "value": round(8.0 * b1.value / s1.value / 1e6, 1),
+                    "mb_per_s": round(m1.value / s1.value, 1),
+                    "sample": "%d slices, %.1f s" % (n_1, s1.value)},
             }
 
     ms_per_step = 1e3 * elapsed / args.steps
