@@ -47,8 +47,19 @@ def make_workload(n_slices, seed0, threads):
                      pm_i16x16=280, pm_pcm=2, density=5, pm_escape=5,
                      pm_cbp_zero=50, pm_zero_pcm=100, seed=seed0 + i)
         slices.append(s)
-    buf, offs, sizes = gen.batch(cfg, slices, threads=threads)
-    return cfg, buf, offs, sizes
+    # in chunks: the generator reserves a worst-case slot per slice (all I_PCM,
+    # 13 MB at 1080p) before it compacts, 53 GB of address space for 4096
+    # slices at once -- times eight ranks on one host
+    bufs, offs, sizes, pos = [], [], [], 0
+    for k in range(0, n_slices, 512):
+        b, o, z = gen.batch(cfg, slices[k:k + 512], threads=threads)
+        pad = (-len(b)) % 16
+        bufs.append(np.concatenate([b, np.zeros(pad, dtype=np.uint8)]))
+        offs.append(o + np.uint64(pos))
+        sizes.append(z)
+        pos += len(b) + pad
+    return (cfg, np.concatenate(bufs), np.concatenate(offs),
+            np.concatenate(sizes))
 
 
 def run_c4(args, eng, dist, rank, world, cores):
