@@ -694,6 +694,35 @@ __device__ __forceinline__ uint32_t sd_scan_add(uint32_t x)
 	return v;
 }
 
+/* levelCode -> level value in lane i, and the suffixLength adaptation (9.2.2.1;
+ * ref src/h264_syntax_slice_data.h:182-202), in full generality */
+__device__ __forceinline__ void sd_level_finish(uint32_t code, uint32_t &suffix_len,
+						uint32_t &lv, uint32_t i,
+						uint32_t lane)
+{
+	/* even code -> +(code + 2) / 2, odd -> -(code + 1) / 2.  The value itself
+	 * is only needed in lane i: it is formed on the vector unit (the copy of
+	 * `code` is made opaque so that the arithmetic stays there); the scalar
+	 * unit keeps just the magnitude for suffix_len */
+	uint32_t mag = (code + 2u) >> 1;
+	{
+		uint32_t cv = code;
+		asm("" : "+v"(cv));
+		uint32_t ng = cv & 1u;
+		uint32_t vv = ((((cv + 2u) >> 1) ^ (0u - ng)) + ng) & 0xffffu;
+		lv = lane == i ? vv : lv;
+	}
+	if (mag > 32767u) {
+		/* levelVal is int16_t in the reference: after an escape the
+		 * magnitude that drives suffix_len is the wrapped one */
+		uint32_t neg = code & 1u;
+		int32_t v16 = (int16_t)((mag ^ (0u - neg)) + neg);
+		mag = (uint32_t)(v16 < 0 ? -v16 : v16);
+	}
+	suffix_len = suffix_len ? suffix_len : 1u;
+	suffix_len += (mag > (3u << (suffix_len - 1u)) && suffix_len < 6u) ? 1u : 0u;
+}
+
 /* 9.2 residual_block (ref src/h264_syntax_slice_data.h:103-242).  The decoded
  * levels go to stage[coef_off ...] (int16 units from the record start).
  * Returns an error flag (non-zero: the slice ends with -EIO); tc_out =
@@ -724,7 +753,10 @@ __device__ __forceinline__ uint32_t sd_residual_block(WaveBits &wb, const VlcTab
 	/* levels (9.2.2.1).  first_adj: the first level after fewer than three
 	 * trailing ones cannot be +-1, so its code is offset by 2 */
 	uint32_t first_adj = t1 < 3 ? 2u : 0u;
-	for (; i < tc; i++) {
+	/* The FIRST level in full generality (suffix_len may be 0, first_adj);
+	 * every later one finds suffix_len >= 1 and no adjustment, which the loop
+	 * below exploits. */
+	if (i < tc) {
 		uint32_t bits = wb_peek(wb, lane);
 		uint32_t prefix = (uint32_t)__builtin_clz(bits | 0x3fu);
 		uint32_t code;
@@ -747,28 +779,35 @@ __device__ __forceinline__ uint32_t sd_residual_block(WaveBits &wb, const VlcTab
 				code += (1u << (prefix - 3u)) - 4096u;
 		}
 		code += first_adj;
-		first_adj = 0;
-		/* even code -> +(code + 2) / 2, odd -> -(code + 1) / 2.  The value
-		 * itself is only needed in lane i: it is formed on the vector unit
-		 * (the copy of `code` is made opaque so that the arithmetic stays
-		 * there); the scalar unit keeps just the magnitude for suffix_len */
-		uint32_t mag = (code + 2u) >> 1;
-		{
-			uint32_t cv = code;
+		sd_level_finish(code, suffix_len, lv, i, lane);
+		i++;
+	}
+	for (; i < tc; i++) {
+		uint32_t bits = wb_peek(wb, lane);
+		uint32_t prefix = (uint32_t)__builtin_clz(bits | 0x3fu);
+		if (prefix < 15u) {
+			/* the usual shape with 1 <= suffix_len <= 6.  levelCode =
+			 * (prefix << suffix_len) + suffix lies below 3 << suffix_len
+			 * exactly when prefix < 3, so suffix_len grows iff prefix >= 3
+			 * -- no magnitude needed on the scalar side */
+			uint32_t suffix = ((bits << (prefix + 1u)) >> 1) >>
+					  (31u - suffix_len);
+			uint32_t cv = (prefix << suffix_len) + suffix;
+			wb_skip(wb, prefix + 1u + suffix_len);
 			asm("" : "+v"(cv));
 			uint32_t ng = cv & 1u;
 			uint32_t vv = ((((cv + 2u) >> 1) ^ (0u - ng)) + ng) & 0xffffu;
 			lv = lane == i ? vv : lv;
+			suffix_len += (prefix >= 3u && suffix_len < 6u) ? 1u : 0u;
+		} else {
+			err |= bits < (1u << 6) ? 1u : 0u; /* level_prefix > 25 */
+			wb_skip(wb, prefix + 1u);
+			uint32_t code = 15u << suffix_len;
+			code += wb_u(wb, lane, prefix - 3u);
+			if (prefix >= 16)
+				code += (1u << (prefix - 3u)) - 4096u;
+			sd_level_finish(code, suffix_len, lv, i, lane);
 		}
-		if (mag > 32767u) {
-			/* levelVal is int16_t in the reference: after an escape the
-			 * magnitude that drives suffix_len is the wrapped one */
-			uint32_t neg = code & 1u;
-			int32_t v16 = (int16_t)((mag ^ (0u - neg)) + neg);
-			mag = (uint32_t)(v16 < 0 ? -v16 : v16);
-		}
-		suffix_len = suffix_len ? suffix_len : 1u;
-		suffix_len += (mag > (3u << (suffix_len - 1u)) && suffix_len < 6u) ? 1u : 0u;
 	}
 	uint32_t zeros_left = 0;
 	if (tc < maxnum)
