@@ -790,15 +790,19 @@ __device__ __forceinline__ uint32_t sd_residual_block(WaveBits &wb, const VlcTab
 			 * (prefix << suffix_len) + suffix lies below 3 << suffix_len
 			 * exactly when prefix < 3, so suffix_len grows iff prefix >= 3
 			 * -- no magnitude needed on the scalar side */
-			uint32_t suffix = ((bits << (prefix + 1u)) >> 1) >>
-					  (31u - suffix_len);
-			uint32_t cv = (prefix << suffix_len) + suffix;
-			wb_skip(wb, prefix + 1u + suffix_len);
+			/* the n = prefix + 1 + suffix_len bits of the code word end in
+			 * "1 suffix": x = 2^suffix_len + suffix, and
+			 * (prefix << suffix_len) + suffix = ((prefix - 1) << suffix_len) + x */
+			const uint32_t n = prefix + 1u + suffix_len;
+			uint32_t cv = ((prefix - 1u) << suffix_len) + (bits >> (32u - n));
+			wb_skip(wb, n);
 			asm("" : "+v"(cv));
 			uint32_t ng = cv & 1u;
 			uint32_t vv = ((((cv + 2u) >> 1) ^ (0u - ng)) + ng) & 0xffffu;
 			lv = lane == i ? vv : lv;
-			suffix_len += (prefix >= 3u && suffix_len < 6u) ? 1u : 0u;
+			/* (suffix_len never exceeds 6: add-with-carry and a minimum) */
+			uint32_t grown = suffix_len + (prefix >= 3u ? 1u : 0u);
+			suffix_len = grown < 6u ? grown : 6u;
 		} else {
 			err |= bits < (1u << 6) ? 1u : 0u; /* level_prefix > 25 */
 			wb_skip(wb, prefix + 1u);
