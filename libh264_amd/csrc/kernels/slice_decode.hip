@@ -760,6 +760,20 @@ __device__ __forceinline__ uint32_t sd_residual_block(WaveBits &wb, const VlcTab
 		uint32_t bits = wb_peek(wb, lane);
 		uint32_t prefix = (uint32_t)__builtin_clz(bits | 0x3fu);
 		uint32_t code;
+		if (suffix_len == 0 && prefix < 14u) {
+			/* by far the most frequent start of a block: no suffix, the
+			 * code is the prefix (+ first_adj); suffixLength becomes 1,
+			 * and 2 when the magnitude (code + 2) >> 1 exceeds 3 */
+			uint32_t cv = prefix + first_adj;
+			wb_skip(wb, prefix + 1u);
+			suffix_len = cv >= 6u ? 2u : 1u;
+			asm("" : "+v"(cv));
+			uint32_t ng = cv & 1u;
+			uint32_t vv = ((((cv + 2u) >> 1) ^ (0u - ng)) + ng) & 0xffffu;
+			lv = lane == i ? vv : lv;
+			i++;
+			goto first_done;
+		}
 		if (prefix < 14u + (suffix_len ? 1u : 0u)) {
 			/* the usual shape: prefix zeros, a one, suffix_len bits,
 			 * all inside the 32 bits at hand */
@@ -782,6 +796,7 @@ __device__ __forceinline__ uint32_t sd_residual_block(WaveBits &wb, const VlcTab
 		sd_level_finish(code, suffix_len, lv, i, lane);
 		i++;
 	}
+first_done:
 	for (; i < tc; i++) {
 		uint32_t bits = wb_peek(wb, lane);
 		uint32_t prefix = (uint32_t)__builtin_clz(bits | 0x3fu);
