@@ -735,7 +735,8 @@ __device__ __forceinline__ uint32_t sd_residual_block(WaveBits &wb, const VlcTab
 						      uint32_t &tc_out)
 {
 	uint32_t t1, tc;
-	uint32_t err = vlc_coeff_token(vt, wb, lane, cls, t1, tc);
+	uint32_t rest;
+	uint32_t err = vlc_coeff_token(vt, wb, lane, cls, t1, tc, rest);
 	tc_out = tc;
 	if (tc == 0)
 		return err;
@@ -745,7 +746,9 @@ __device__ __forceinline__ uint32_t sd_residual_block(WaveBits &wb, const VlcTab
 	uint32_t i = 0;
 	if (t1) {
 		/* trailing ones: bit (t1 - 1 - i) of the sign field is level i */
-		uint32_t signs = wb_u(wb, lane, t1);
+		/* the token is at most 16 bits long: its peek still holds them */
+		uint32_t signs = rest >> (32u - t1);
+		wb_skip(wb, t1);
 		uint32_t sbit = (signs >> ((t1 - 1u - lane) & 31u)) & 1u;
 		lv = lane < t1 ? (sbit ? 0xffffu : 1u) : 0u;
 		i = t1;

@@ -103,7 +103,8 @@ __device__ __forceinline__ uint32_t vlc_ct_class(uint32_t nC)
  * 4:2:2).  Returns the bad flag. */
 __device__ __forceinline__ uint32_t vlc_coeff_token(const VlcTabs &t, WaveBits &s,
 						    uint32_t lane, uint32_t cls,
-						    uint32_t &t1, uint32_t &tc)
+						    uint32_t &t1, uint32_t &tc,
+						    uint32_t &rest)
 {
 	uint32_t bits = wb_peek(s, lane);
 	uint32_t bad;
@@ -113,6 +114,9 @@ __device__ __forceinline__ uint32_t vlc_coeff_token(const VlcTabs &t, WaveBits &
 	wb_skip(s, cw & 31u);
 	t1 = (cw >> 5) & 3u;
 	tc = (cw >> 7) & 31u;
+	/* what the peek holds behind the token (at least 16 bits): the
+	 * trailing-one signs need no second peek */
+	rest = bits << (cw & 31u);
 	return bad;
 }
 
