@@ -837,10 +837,18 @@ first_done:
 	for (i = 0; i + 1 < tc && zeros_left > 0; i++) {
 		uint32_t run;
 		zl = wb_setlane(zl, i, zeros_left, lane);
-		err |= vlc_run_before(vt, wb, lane, zeros_left, run);
-		uint32_t over = run > zeros_left ? 1u : 0u;
-		err |= over;
-		zeros_left -= over ? zeros_left : run;
+		if (zeros_left > 6) {
+			err |= vlc_run_before(vt, wb, lane, zeros_left, run);
+			uint32_t over = run > zeros_left ? 1u : 0u;
+			err |= over;
+			zeros_left -= over ? zeros_left : run;
+		} else {
+			/* Table 9-10 for zerosLeft <= 6 only has runs up to
+			 * zerosLeft and a code word for every 3-bit pattern:
+			 * nothing to check */
+			vlc_run_before(vt, wb, lane, zeros_left, run);
+			zeros_left -= run;
+		}
 	}
 	zl = wb_setlane(zl, tc - 1u, zeros_left, lane);
 	/* lane i places coefficient i */
