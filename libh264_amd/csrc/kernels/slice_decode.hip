@@ -730,13 +730,15 @@ __device__ __forceinline__ void sd_level_finish(uint32_t code, uint32_t &suffix_
  * walk goes on with benign values until the caller looks at it. */
 __device__ __forceinline__ uint32_t sd_residual_block(WaveBits &wb, const VlcTabs &vt,
 						      uint32_t lane, uint8_t *stage,
-						      uint32_t cls,
+						      uint32_t cls, uint32_t peek,
 						      uint32_t maxnum, uint32_t coef_off,
 						      uint32_t &tc_out)
 {
 	uint32_t t1, tc;
 	uint32_t rest;
-	uint32_t err = vlc_coeff_token(vt, wb, lane, cls, t1, tc, rest);
+	/* peek: the 32 bits at the cursor (the block loop looked at them for its
+	 * empty-run test) */
+	uint32_t err = vlc_coeff_token(vt, wb, lane, cls, peek, t1, tc, rest);
 	tc_out = tc;
 	if (tc == 0)
 		return err;
@@ -1374,7 +1376,7 @@ sd_slice_data(WaveBits &wb, const VlcTabs &vt, uint32_t cbp_map, uint32_t lane,
 						(int)sd_class_all(m, lane, cat),
 						(int)(info >> 24));
 					err |= sd_residual_block(
-						wb, vt, lane, stage, cls,
+						wb, vt, lane, stage, cls, peek,
 						(info >> 6) & 31u,
 						(info >> 13) & 0x7ffu, tc);
 					/* TotalCoeff is recorded for every class, DC

@@ -103,10 +103,10 @@ __device__ __forceinline__ uint32_t vlc_ct_class(uint32_t nC)
  * 4:2:2).  Returns the bad flag. */
 __device__ __forceinline__ uint32_t vlc_coeff_token(const VlcTabs &t, WaveBits &s,
 						    uint32_t lane, uint32_t cls,
-						    uint32_t &t1, uint32_t &tc,
-						    uint32_t &rest)
+						    uint32_t bits, uint32_t &t1,
+						    uint32_t &tc, uint32_t &rest)
 {
-	uint32_t bits = wb_peek(s, lane);
+	/* bits: the peek at the cursor, which the caller already has */
 	uint32_t bad;
 	int hit;
 	uint32_t cw = vlc_match(t.ct + 512u * cls, t.off64, bits, bad, hit);
