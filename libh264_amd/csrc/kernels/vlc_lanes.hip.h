@@ -128,13 +128,13 @@ __device__ __forceinline__ uint32_t vlc_total_zeros(const VlcTabs &t, WaveBits &
 						    uint32_t maxnum, uint32_t &tz)
 {
 	uint32_t bits = wb_peek(s, lane);
+	/* 1 <= tc < maxnum and maxnum in {4, 8, 15, 16} (the callers' block
+	 * constants) keep k inside the 25 tables: tc - 1 <= 14, 14 + tc <= 17,
+	 * 17 + tc <= 24 */
 	uint32_t k = maxnum == 4 ? 14u + tc : maxnum == 8 ? 17u + tc : tc - 1u;
-	uint32_t range = k >= DEV_VLC_TZ_TABLES ? 1u : 0u;
-	k = range ? 0u : k;
 	uint32_t bad;
 	int hit;
 	uint32_t cw = vlc_match(t.tz + 128u * k, t.off16, bits, bad, hit);
-	bad |= range;
 	uint32_t okm = bad - 1u;
 	wb_skip(s, cw & 31u & okm);
 	tz = (uint32_t)hit & okm;
