@@ -86,6 +86,28 @@ def test_synthetic_slice_known_sizes():
                       mb_count=8160)) == 63
 
 
+def test_survey_probe_stream_size():
+    """the survey's probe stream -- SPS, PPS and 64 grey
+    1080p IDR slices behind four-byte start codes -- was 522 774 bytes on the
+    real reference; the oracle's writer builds the same number of bytes and its
+    reader walks 64 x 8160 macroblocks out of them."""
+    b = orc.Builder()
+    sps, pps = ps_1080p(0)
+    sh = SliceHeader()
+    sh.slice_type = 7
+    nals = [b.nalu(3, 7, sps=sps), b.nalu(3, 8, sps=sps, pps=pps)]
+    for k in range(64):
+        sh.idr_pic_id = 0
+        nals.append(b.nalu(3, 5, sps=sps, pps=pps, sh=sh, kind=1,
+                           mb_count=8160))
+    data = b"".join(b"\x00\x00\x00\x01" + n for n in nals)
+    assert len(data) == 522774
+    rec = orc.parse_stream(data, want=0)
+    assert rec.consumed == len(data) and len(rec.nals) == 66
+    assert [r.mb_count for r in rec.results] == [8160] * 64
+    assert all(r.status == 0 for r in rec.results)
+
+
 class Bits:
     def __init__(self):
         self.v = 0
