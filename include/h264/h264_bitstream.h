@@ -194,7 +194,9 @@ static inline int h264_bs_read_bits_se(struct h264_bitstream *bs, int32_t *v)
 
 static inline int h264_bs_write_bits_se(struct h264_bitstream *bs, int32_t v)
 {
-	uint32_t k = v > 0 ? (uint32_t)(2 * v - 1) : (uint32_t)(-2 * v);
+	/* unsigned arithmetic: the same bits as the reference's signed products,
+	 * defined for |v| >= 2^30 as well */
+	uint32_t k = v > 0 ? 2u * (uint32_t)v - 1u : 0u - 2u * (uint32_t)v;
 	return h264_bs_write_bits_ue(bs, k);
 }
 

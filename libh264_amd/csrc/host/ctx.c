@@ -48,12 +48,19 @@ static void derive_from_slice(struct h264_ctx *ctx)
 	ctx->derived.MaxPicNum = sd->MaxFrameNum * (sh->field_pic_flag ? 2 : 1);
 	ctx->derived.CurrPicNum =
 		sh->field_pic_flag ? 2 * sh->frame_num + 1 : sh->frame_num;
+	/* unsigned arithmetic throughout: a damaged stream carries any 32-bit
+	 * se(v) here, and the reference's signed sums / left shifts of negative
+	 * values are undefined for them (same bits where they are defined) */
 	ctx->derived.SliceQPLuma =
-		26 + ctx->pps->pic_init_qp_minus26 + sh->slice_qp_delta;
+		(int32_t)(26u + (uint32_t)ctx->pps->pic_init_qp_minus26 +
+			  (uint32_t)sh->slice_qp_delta);
 	ctx->derived.QSLuma =
-		26 + ctx->pps->pic_init_qs_minus26 + sh->slice_qs_delta;
-	ctx->derived.FilterOffsetA = sh->slice_alpha_c0_offset_div2 << 1;
-	ctx->derived.FilterOffsetB = sh->slice_beta_offset_div2 << 1;
+		(int32_t)(26u + (uint32_t)ctx->pps->pic_init_qs_minus26 +
+			  (uint32_t)sh->slice_qs_delta);
+	ctx->derived.FilterOffsetA =
+		(int32_t)((uint32_t)sh->slice_alpha_c0_offset_div2 * 2u);
+	ctx->derived.FilterOffsetB =
+		(int32_t)((uint32_t)sh->slice_beta_offset_div2 * 2u);
 	cycle = sh->slice_group_change_cycle * ctx->derived.SliceGroupChangeRate;
 	ctx->derived.MapUnitsInSliceGroup0 =
 		cycle < sd->PicSizeInMapUnits ? cycle : sd->PicSizeInMapUnits;

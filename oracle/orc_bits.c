@@ -327,9 +327,11 @@ int orc_bs_write_ue(struct h264_bitstream *bs, uint32_t v)
 
 int orc_bs_write_se(struct h264_bitstream *bs, int32_t v)
 {
+	/* the reference multiplies the signed value (include/h264/h264_bitstream.h
+	 * :277-290): same bits, but defined for |v| >= 2^30 too */
 	if (v <= 0)
-		return orc_bs_write_ue(bs, (uint32_t)(-2 * v));
-	return orc_bs_write_ue(bs, (uint32_t)(2 * v - 1));
+		return orc_bs_write_ue(bs, 0u - 2u * (uint32_t)v);
+	return orc_bs_write_ue(bs, 2u * (uint32_t)v - 1u);
 }
 
 int orc_bs_write_te(struct h264_bitstream *bs, uint32_t v, uint32_t m)

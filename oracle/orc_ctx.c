@@ -104,10 +104,16 @@ static void update_derived_slice(struct orc_ctx *ctx)
 	ctx->derived.CurrPicNum =
 		sh->field_pic_flag ? 2 * sh->frame_num + 1 : sh->frame_num;
 	ctx->derived.SliceQPLuma =
-		pps->pic_init_qp_minus26 + 26 + sh->slice_qp_delta;
-	ctx->derived.QSLuma = pps->pic_init_qs_minus26 + 26 + sh->slice_qs_delta;
-	ctx->derived.FilterOffsetA = sh->slice_alpha_c0_offset_div2 << 1;
-	ctx->derived.FilterOffsetB = sh->slice_beta_offset_div2 << 1;
+		(int32_t)((uint32_t)pps->pic_init_qp_minus26 + 26u +
+			  (uint32_t)sh->slice_qp_delta); /* wraps, defined */
+	ctx->derived.QSLuma = (int32_t)((uint32_t)pps->pic_init_qs_minus26 + 26u +
+					(uint32_t)sh->slice_qs_delta);
+	/* (the reference shifts the signed value left, src/h264_ctx.c:116-117;
+	 * same result, defined) */
+	ctx->derived.FilterOffsetA =
+		(int32_t)((uint32_t)sh->slice_alpha_c0_offset_div2 * 2u);
+	ctx->derived.FilterOffsetB =
+		(int32_t)((uint32_t)sh->slice_beta_offset_div2 * 2u);
 	ctx->derived.MapUnitsInSliceGroup0 =
 		ORC_MIN(sh->slice_group_change_cycle *
 				ctx->derived.SliceGroupChangeRate,
