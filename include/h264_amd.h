@@ -306,7 +306,11 @@ struct h264_amd_decode_args {
 	uint32_t n;
 	uint32_t reader_flags; /* H264_READER_FLAGS_SLICE_DATA or 0 */
 	uint32_t tier; /* enum h264_amd_tier */
-	uint32_t mb_capacity; /* macroblock records per slice */
+	/* macroblock records per slice; a slice with more macroblocks ends with
+	 * H264_AMD_E_MB_OVERFLOW.  0 is only accepted without macroblock output
+	 * (tier NONE or d_mb_out NULL) and then means "no limit other than
+	 * H264_AMD_MAX_SLICE_MBS" */
+	uint32_t mb_capacity;
 	struct h264_amd_slice_result *d_results; /* [n] */
 	struct h264_slice_header *d_headers; /* [n] byte images, or NULL */
 	uint8_t *d_mb_out; /* n * mb_capacity * mb_stride bytes, or NULL */

@@ -28,7 +28,10 @@ def engine_lib():
     global _LIB
     if _LIB is not None:
         return _LIB
-    path = os.path.join(HERE, "lib", "libh264_amd_engine.so")
+    # H264_AMD_ENGINE_LIB: development knob, another build of the same engine
+    # (tools/ab_decode.py times kernel variants side by side)
+    path = os.environ.get("H264_AMD_ENGINE_LIB") or \
+        os.path.join(HERE, "lib", "libh264_amd_engine.so")
     if not os.path.exists(path):
         raise EngineError(
             2, "%s missing: run `python -m libh264_amd.build`" % path)
@@ -220,8 +223,6 @@ class Engine:
             d_descs = self.upload(arr)
         stride = {TIER_NONE: 0, TIER_T0: 4, TIER_T1: 64,
                   TIER_T2: t2_stride(3)}[tier]
-        if tier == TIER_T2 and cat is not None:
-            stride = t2_stride(cat) if False else t2_stride(3)
         out = outputs or {}
         if "results" not in out:
             out["results"] = self.alloc(n * C.sizeof(SliceResult))

@@ -209,16 +209,26 @@ extern "C" int h264_amd_engine_new(int device, void *hip_stream,
 	if (e == NULL)
 		return -ENOMEM;
 	memset(e, 0, sizeof(*e));
+	/* a failure from here on releases what exists so far */
+#define NEW_TRY(x)                                                             \
+	do {                                                                   \
+		hipError_t err_ = (x);                                         \
+		if (err_ != hipSuccess) {                                      \
+			int rc_ = hip_err(err_);                               \
+			h264_amd_engine_destroy(e);                            \
+			return rc_;                                            \
+		}                                                              \
+	} while (0)
 	e->device = device;
 	if (hip_stream != NULL) {
 		e->stream = (hipStream_t)hip_stream;
 	} else {
-		HIP_TRY(hipStreamCreateWithFlags(&e->stream, hipStreamNonBlocking));
+		NEW_TRY(hipStreamCreateWithFlags(&e->stream, hipStreamNonBlocking));
 		e->own_stream = true;
 	}
 	for (int f = 0; f < FAM_COUNT; f++)
 		for (int k = 0; k < 2; k++)
-			HIP_TRY(hipEventCreate(&e->ev[f][k]));
+			NEW_TRY(hipEventCreate(&e->ev[f][k]));
 	{
 		const char *v = getenv("H264_AMD_SCAN_SEG");
 		unsigned long seg = v ? strtoul(v, NULL, 0) : 0;
@@ -229,17 +239,18 @@ extern "C" int h264_amd_engine_new(int device, void *hip_stream,
 	{
 		dev_vlc_tables *h = new dev_vlc_tables;
 		vlc_build_tables(h);
-		HIP_TRY(hipMalloc((void **)&e->d_vlc, sizeof(*h)));
-		HIP_TRY(hipMemcpy(e->d_vlc, h, sizeof(*h), hipMemcpyHostToDevice));
+		NEW_TRY(hipMalloc((void **)&e->d_vlc, sizeof(*h)));
+		NEW_TRY(hipMemcpy(e->d_vlc, h, sizeof(*h), hipMemcpyHostToDevice));
 		delete h;
 	}
 	{
 		cabac_tables *h = new cabac_tables;
 		cabac_build_tables(h);
-		HIP_TRY(hipMalloc((void **)&e->d_cabac, sizeof(*h)));
-		HIP_TRY(hipMemcpy(e->d_cabac, h, sizeof(*h), hipMemcpyHostToDevice));
+		NEW_TRY(hipMalloc((void **)&e->d_cabac, sizeof(*h)));
+		NEW_TRY(hipMemcpy(e->d_cabac, h, sizeof(*h), hipMemcpyHostToDevice));
 		delete h;
 	}
+#undef NEW_TRY
 	*ret = e;
 	return 0;
 }
@@ -249,10 +260,12 @@ extern "C" int h264_amd_engine_destroy(struct h264_amd_engine *e)
 	if (e == NULL)
 		return 0;
 	hipSetDevice(e->device);
-	hipStreamSynchronize(e->stream);
+	if (e->stream != NULL)
+		hipStreamSynchronize(e->stream);
 	for (int f = 0; f < FAM_COUNT; f++)
 		for (int k = 0; k < 2; k++)
-			hipEventDestroy(e->ev[f][k]);
+			if (e->ev[f][k] != NULL)
+				hipEventDestroy(e->ev[f][k]);
 	hipFree(e->d_vlc);
 	hipFree(e->d_cabac);
 	hipFree(e->d_sps);
@@ -573,6 +586,8 @@ extern "C" int h264_amd_decode_slices(struct h264_amd_engine *e,
 	a.reader_flags = args->reader_flags;
 	a.tier = args->d_mb_out ? args->tier : (uint32_t)H264_AMD_TIER_NONE;
 	a.mb_capacity = args->mb_capacity;
+	if (a.mb_capacity == 0 && a.tier == H264_AMD_TIER_NONE)
+		a.mb_capacity = H264_AMD_MAX_SLICE_MBS; /* nothing to overflow */
 	a.mb_stride = stride;
 	a.results = args->d_results;
 	a.headers = args->d_headers;

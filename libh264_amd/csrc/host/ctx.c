@@ -162,6 +162,7 @@ int h264_ctx_clear(struct h264_ctx *ctx)
 {
 	size_t i;
 	struct h264_amd_params *wp;
+	uint64_t gen;
 	if (ctx == NULL)
 		return -EINVAL;
 	h264_ctx_clear_nalu(ctx);
@@ -170,9 +171,14 @@ int h264_ctx_clear(struct h264_ctx *ctx)
 	for (i = 0; i < H264_ARRAY_SIZE(ctx->pps_table); i++)
 		free(ctx->pps_table[i]);
 	wp = ctx->wr_params;
+	gen = ctx->ps_generation;
 	memset(ctx, 0, sizeof(*ctx));
 	ctx->wr_params = wp;
-	ctx->ps_generation = 1; /* invalidates the writer's snapshot */
+	/* the counter never repeats: the reader's and the writer's snapshots
+	 * compare generations for equality, and a counter reset to a constant
+	 * would meet an old value again after as many set_sps / set_pps calls
+	 * as came before the clear -- with other parameter sets behind it */
+	ctx->ps_generation = gen + 1;
 	return 0;
 }
 

@@ -107,6 +107,27 @@ def test_header_only(engine):
     run_case(engine, cfg, slices, TIER_NONE, flags=0)
 
 
+def test_walk_without_macroblock_output_needs_no_capacity(engine):
+    """reader_flags = SLICE_DATA, tier NONE and mb_capacity left at 0 walks
+    the slice data (include/h264_amd.h: 0 = no limit without macroblock
+    output); it used to end every slice with H264_AMD_E_MB_OVERFLOW."""
+    cfg = streams.small_cfg()
+    slices = [streams.rich_slice(cfg, seed, st)
+              for seed in range(6) for st in (2, 0, 1)]
+    nals = [gen.slice_nal(cfg, s) for s in slices]
+    ref = orc.parse_nalus([gen.sps(cfg), gen.pps(cfg)] + nals, flags=1)
+    params = make_params(ref)
+    buf, offs, sizes = streams.pack_nals(nals)
+    d_buf = engine.upload(buf)
+    descs = [(o, s, params.epoch) for o, s in zip(offs, sizes)]
+    out = engine.decode_slices(params, d_buf, descs, reader_flags=1,
+                               tier=TIER_NONE)
+    res = engine.fetch_results(out)
+    for i, s in enumerate(slices):
+        assert result_fields(res[i]) == result_fields(ref.results[i]), i
+        assert res[i].status == 0 and res[i].mb_count == s.num_mbs
+
+
 def test_1080p_slice(engine):
     cfg = gen.cfg_1080p()
     slices = [streams.rich_slice(cfg, 7, 7, pm_pcm=2, density=5,

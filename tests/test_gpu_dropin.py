@@ -370,3 +370,61 @@ def test_write_nalu_slice_header_only_and_rewrite():
                                        C.byref(sh3)) == -71  # -EPROTO
     assert patched.raw == before
     ctx.close()
+
+
+def test_ctx_clear_then_other_parameter_sets():
+    """h264_ctx_clear() followed by as many set_sps / set_pps calls as came
+    before it must not leave the reader's (or the writer's) device snapshot of
+    the parameter sets in place: the generation counter they compare never
+    repeats (libh264_amd/csrc/host/ctx.c)."""
+    L, H = prod.recorder(), prod.h264()
+    a = streams.small_cfg()
+    b = streams.small_cfg(width_mbs=5, height_mbs=4, chroma_format_idc=2)
+    first = [gen.sps(a), gen.pps(a),
+             gen.slice_nal(a, streams.rich_slice(a, 3, 2))]
+    second = [gen.sps(b), gen.pps(b),
+              gen.slice_nal(b, streams.rich_slice(b, 4, 2)),
+              gen.slice_nal(b, streams.rich_slice(b, 5, 0))]
+    rec = L.rec_new(1, 0)
+    keep = []
+
+    def feed(nal):
+        buf = C.create_string_buffer(bytes(nal), len(nal))
+        keep.append(buf)
+        return L.rec_parse_nalu(rec, C.addressof(buf), C.addressof(buf),
+                                len(nal))
+
+    assert [feed(n) for n in first] == [0, 0, 0]
+    n_before = len(prod.Recording(rec, keep).event_tuples())
+    assert H.h264_ctx_clear(L.rec_ctx(rec)) == 0
+    assert [feed(n) for n in second] == [0, 0, 0, 0]
+    got = prod.Recording(rec, keep)
+    L.rec_free(rec)
+    ref = orc.parse_nalus(second, want=0)
+    assert ref.statuses == [0, 0, 0, 0]
+    assert got.event_tuples()[n_before:] == ref.event_tuples()
+    assert bytes(got.headers)[-2 * C.sizeof(SliceHeader):] == \
+        bytes(ref.headers)
+
+    # the writer side: same sequence through a plain h264_ctx; a header
+    # written under B must be the header of the NAL generated under B (frame
+    # number width, chroma format and picture size all differ from A)
+    sa, pa = parsed_sets(a)
+    sb, pb = parsed_sets(b)
+    nal = second[3]
+    hb = C.sizeof(SliceHeader)
+    sh = SliceHeader.from_buffer_copy(bytes(ref.headers)[hb:2 * hb])
+    r = ref.results[1]
+    ctx = Ctx(sa, pa)
+    ctx.slice(1, 1, SliceHeader())
+    bs, buf = new_bs()
+    assert H.h264_write_nalu(C.byref(bs), ctx.p) == 0
+    assert H.h264_ctx_clear(ctx.p) == 0
+    assert H.h264_ctx_set_sps(ctx.p, C.byref(sb)) == 0
+    assert H.h264_ctx_set_pps(ctx.p, C.byref(pb)) == 0
+    ctx.slice(r.nal_ref_idc, r.nal_unit_type, sh)
+    bs2, buf2 = new_bs()
+    assert H.h264_write_nalu(C.byref(bs2), ctx.p) == 0
+    assert 8 * bs2.off + bs2.cachebits == r.hdr_len_bits
+    assert buf2.raw[:bs2.off] == nal[:bs2.off]
+    ctx.close()
