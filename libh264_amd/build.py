@@ -66,7 +66,14 @@ def build_engine(force=False):
     out = os.path.join(LIB, "libh264_amd_engine.so")
     srcs = _tree(CSRC, INC)
     if force or _newer(out, srcs):
-        opt = os.environ.get("H264_AMD_HIPCC_OPT", "-O3").split()
+        # -structurizecfg-skip-uniform-regions: the decode kernel's control
+        # flow is wave-uniform by construction; without the flag the backend
+        # still threads uniform regions through the structurizer's flow blocks
+        # (s_mov -1 / s_andn2 vcc, exec / s_cbranch_vccnz chains): 17 % more
+        # scalar instructions, 4 % more time (profiles/r02_decode_cost_model.md)
+        opt = os.environ.get(
+            "H264_AMD_HIPCC_OPT",
+            "-O3 -mllvm -structurizecfg-skip-uniform-regions").split()
         _run([_hipcc(), "--offload-arch=gfx950"] + opt + ["-std=c++17", "-fPIC",
               "-shared", "-Wno-unused-value", "-I" + INC, "-I" + CSRC,
               os.path.join(CSRC, "engine.hip"), "-o", out])

@@ -44,6 +44,7 @@
 #include <h264_amd.h>
 
 #include "dev_params.h"
+#include "vbits.hip.h"
 #include "vlc_lanes.hip.h"
 #include "wave_bits.hip.h"
 
@@ -641,14 +642,17 @@ __device__ __forceinline__ uint32_t sd_gather(uint32_t table, uint32_t idx)
 	return idx >= 64u ? idx : v;
 }
 
-__device__ __forceinline__ uint32_t sd_intra_pred_modes(WaveBits &wb, uint32_t lane,
-							uint32_t n, uint8_t *stage)
+__device__ __forceinline__ uint32_t sd_intra_pred_modes(const VBits &vb,
+							const WaveBits &wb,
+							uint32_t lane, uint32_t n,
+							uint8_t *stage)
 {
-	uint32_t hi = wb_peek(wb, lane);
-	wb.bitpos += 32u;
-	uint32_t lo = wb_peek(wb, lane);
-	wb.bitpos -= 32u;
-	const uint64_t win = ((uint64_t)hi << 32) | lo;
+	/* the 64 bits at the cursor (vo < 32: the caller has normalised): what W
+	 * holds, then the top of the window dword behind it */
+	uint32_t d2 = (uint32_t)__builtin_amdgcn_readlane((int)wb.wnext,
+							   (int)(vb.sd + 1u));
+	VB_VREG(d2);
+	const uint64_t win = (vb.W << vb.vo) | ((d2 >> 1) >> (31u - vb.vo));
 	uint32_t flag = (uint32_t)(win >> (63u - lane)) & 1u;
 	uint32_t j1 = lane + (flag ? 1u : 4u);
 	uint32_t j2 = sd_gather(j1, j1);
@@ -694,24 +698,37 @@ __device__ __forceinline__ uint32_t sd_scan_add(uint32_t x)
 	return v;
 }
 
-/* levelCode -> level value in lane i, and the suffixLength adaptation (9.2.2.1;
- * ref src/h264_syntax_slice_data.h:182-202), in full generality */
-__device__ __forceinline__ void sd_level_finish(uint32_t code, uint32_t &suffix_len,
-						uint32_t &lv, uint32_t i,
-						uint32_t lane)
+/* One level the long way (9.2.2.1; ref src/h264_syntax_slice_data.h:156-202):
+ * level_prefix of 14 and more with suffixLength 0, 15 and more otherwise (the
+ * escape codes).  Rare, so it runs on the scalar cursor: returns levelCode
+ * (first_adj included) and moves suffix_len on.  bad: level_prefix > 25. */
+__device__ __forceinline__ uint32_t sd_level_escape(WaveBits &wb, uint32_t lane,
+						    uint32_t &suffix_len,
+						    uint32_t first_adj, uint32_t &bad)
 {
-	/* even code -> +(code + 2) / 2, odd -> -(code + 1) / 2.  The value itself
-	 * is only needed in lane i: it is formed on the vector unit (the copy of
-	 * `code` is made opaque so that the arithmetic stays there); the scalar
-	 * unit keeps just the magnitude for suffix_len */
-	uint32_t mag = (code + 2u) >> 1;
-	{
-		uint32_t cv = code;
-		asm("" : "+v"(cv));
-		uint32_t ng = cv & 1u;
-		uint32_t vv = ((((cv + 2u) >> 1) ^ (0u - ng)) + ng) & 0xffffu;
-		lv = lane == i ? vv : lv;
+	uint32_t bits = wb_peek(wb, lane);
+	uint32_t prefix = (uint32_t)__builtin_clz(bits | 0x3fu);
+	uint32_t code;
+	bad |= bits < (1u << 6) ? 1u : 0u; /* level_prefix > 25 */
+	if (prefix < 14u + (suffix_len ? 1u : 0u)) {
+		/* not an escape after all (callers only come here for escapes, but
+		 * the general form costs nothing to keep) */
+		uint32_t suffix = ((bits << (prefix + 1u)) >> 1) >> (31u - suffix_len);
+		code = (prefix << suffix_len) + suffix;
+		wb_skip(wb, prefix + 1u + suffix_len);
+	} else {
+		wb_skip(wb, prefix + 1u);
+		code = (prefix < 15u ? prefix : 15u) << suffix_len;
+		uint32_t size = prefix == 14u ? 4u : prefix - 3u;
+		code += wb_u(wb, lane, size);
+		if (prefix >= 15 && suffix_len == 0)
+			code += 15;
+		if (prefix >= 16)
+			code += (1u << (prefix - 3u)) - 4096u;
 	}
+	code += first_adj;
+	/* even code -> +(code + 2) / 2, odd -> -(code + 1) / 2 */
+	uint32_t mag = (code + 2u) >> 1;
 	if (mag > 32767u) {
 		/* levelVal is int16_t in the reference: after an escape the
 		 * magnitude that drives suffix_len is the wrapped one */
@@ -721,148 +738,186 @@ __device__ __forceinline__ void sd_level_finish(uint32_t code, uint32_t &suffix_
 	}
 	suffix_len = suffix_len ? suffix_len : 1u;
 	suffix_len += (mag > (3u << (suffix_len - 1u)) && suffix_len < 6u) ? 1u : 0u;
+	return code;
 }
 
 /* 9.2 residual_block (ref src/h264_syntax_slice_data.h:103-242).  The decoded
  * levels go to stage[coef_off ...] (int16 units from the record start).
- * Returns an error flag (non-zero: the slice ends with -EIO); tc_out =
- * TotalCoeff.  Malformed codes do not branch out: they raise the flag and the
- * walk goes on with benign values until the caller looks at it. */
-__device__ __forceinline__ uint32_t sd_residual_block(WaveBits &wb, const VlcTabs &vt,
-						      uint32_t lane, uint8_t *stage,
-						      uint32_t cls, uint32_t peek,
-						      uint32_t maxnum, uint32_t coef_off,
-						      uint32_t &tc_out)
+ * Returns TotalCoeff.  Malformed codes do not branch out: they raise a flag
+ * (serr: scalar, verr: any lane) and the walk goes on with benign values until
+ * the caller looks at them.
+ *
+ * Division of labour (profiles/r02_decode_cost_model.md): the bit cursor and
+ * everything decoded from the bits live in wave-uniform VECTOR registers
+ * (vbits.hip.h); the scalar unit keeps the counts that steer loops (TotalCoeff,
+ * TrailingOnes, zerosLeft).  A level is recorded as its levelCode in lane i and
+ * all levels turn into values at once behind the loop; zerosLeft before run i
+ * goes to lane i the same way.
+ *
+ * vb: normalised on entry (vo < 32). */
+__device__ __forceinline__ uint32_t
+sd_residual_block(VBits &vb, WaveBits &wb, const VlcTabs &vt, uint32_t lane,
+		  uint8_t *stage, uint32_t cls, uint32_t bits, uint32_t maxnum,
+		  uint32_t coef_off, uint32_t &serr, uint32_t &verr)
 {
-	uint32_t t1, tc;
-	uint32_t rest;
-	/* peek: the 32 bits at the cursor (the block loop looked at them for its
-	 * empty-run test) */
-	uint32_t err = vlc_coeff_token(vt, wb, lane, cls, peek, t1, tc, rest);
-	tc_out = tc;
+	/* ---- coeff_token; bits: the peek at the cursor, which the block loop
+	 * already has ---- */
+	uint32_t tc, t1, len;
+	{
+		uint32_t bad;
+		int hit;
+		uint32_t cw = vlc_match(vt.ct + 512u * cls, vt.off64, bits, bad, hit);
+		cw &= bad - 1u; /* everything 0 on a bad code */
+		serr |= bad;
+		len = cw & 31u;
+		t1 = (cw >> 5) & 3u;
+		tc = (cw >> 7) & 31u;
+	}
+	vb_skip(vb, len); /* <= 16 bits */
 	if (tc == 0)
-		return err;
-	uint32_t lv = 0; /* per lane: level i */
-	uint32_t zl = 0; /* per lane: zerosLeft before run i */
-	uint32_t suffix_len = (tc > 10 && t1 < 3) ? 1u : 0u;
-	uint32_t i = 0;
-	if (t1) {
-		/* trailing ones: bit (t1 - 1 - i) of the sign field is level i */
-		/* the token is at most 16 bits long: its peek still holds them */
-		uint32_t signs = rest >> (32u - t1);
-		wb_skip(wb, t1);
-		uint32_t sbit = (signs >> ((t1 - 1u - lane) & 31u)) & 1u;
-		lv = lane < t1 ? (sbit ? 0xffffu : 1u) : 0u;
-		i = t1;
+		return 0;
+	/* ---- trailing ones: bit (t1 - 1 - i) of the sign field is level i, i.e.
+	 * bit 31 - i of what the peek holds behind the token (at most 16 bits
+	 * long: the peek still has the signs).  As levelCode: +1 = 0, -1 = 1 ---- */
+	uint32_t codes;
+	{
+		uint32_t rest = bits << len;
+		uint32_t sbit = (rest << lane) >> 31;
+		codes = lane < t1 ? sbit : 0u;
 	}
-	/* levels (9.2.2.1).  first_adj: the first level after fewer than three
-	 * trailing ones cannot be +-1, so its code is offset by 2 */
-	uint32_t first_adj = t1 < 3 ? 2u : 0u;
-	/* The FIRST level in full generality (suffix_len may be 0, first_adj);
-	 * every later one finds suffix_len >= 1 and no adjustment, which the loop
-	 * below exploits. */
+	vb_skip(vb, t1); /* vo <= 31 + 16 + 3 */
+	uint32_t i = t1;
 	if (i < tc) {
-		uint32_t bits = wb_peek(wb, lane);
-		uint32_t prefix = (uint32_t)__builtin_clz(bits | 0x3fu);
-		uint32_t code;
-		if (suffix_len == 0 && prefix < 14u) {
-			/* by far the most frequent start of a block: no suffix, the
-			 * code is the prefix (+ first_adj); suffixLength becomes 1,
-			 * and 2 when the magnitude (code + 2) >> 1 exceeds 3 */
-			uint32_t cv = prefix + first_adj;
-			wb_skip(wb, prefix + 1u);
-			suffix_len = cv >= 6u ? 2u : 1u;
-			asm("" : "+v"(cv));
-			uint32_t ng = cv & 1u;
-			uint32_t vv = ((((cv + 2u) >> 1) ^ (0u - ng)) + ng) & 0xffffu;
-			lv = lane == i ? vv : lv;
-			i++;
-			goto first_done;
+		/* ---- levels (9.2.2.1).  The FIRST one in full generality:
+		 * suffixLength 0 or 1, and after fewer than three trailing ones it
+		 * cannot be +-1, so its code is offset by 2 ---- */
+		const uint32_t first_adj = t1 < 3 ? 2u : 0u;
+		const uint32_t sl0 = (tc > 10 && t1 < 3) ? 1u : 0u;
+		uint32_t sl; /* suffixLength, vector side */
+		vb_norm(vb, wb);
+		{
+			uint32_t b1 = vb_peek(vb);
+			/* 15 stands for "15 or more": the escape path looks again */
+			uint32_t p = (uint32_t)__builtin_clz(b1 | 0x10000u);
+			if (vb_true(p >= 14u + sl0)) {
+				uint32_t ssl = sl0;
+				vb_store(vb, wb);
+				uint32_t code = sd_level_escape(wb, lane, ssl, first_adj,
+								serr);
+				vb_load(vb, wb);
+				sl = ssl;
+				VB_VREG(sl);
+				VB_VREG(code);
+				codes = lane == i ? code : codes;
+			} else {
+				/* prefix zeros, a one, sl0 suffix bits: the n bits of
+				 * the code word end in "1 suffix" = 2^sl0 + suffix, and
+				 * levelCode = (prefix << sl0) + suffix
+				 *           = ((prefix - 1) << sl0) + that */
+				uint32_t n = p + 1u + sl0;
+				uint32_t code = ((p - 1u) << sl0) + (b1 >> (32u - n)) +
+						first_adj;
+				vb_skip(vb, n); /* <= 16 bits */
+				/* suffixLength becomes 1, and 2 when the magnitude
+				 * (code + 2) >> 1 exceeds 3 */
+				sl = code >= 6u ? 2u : 1u;
+				codes = lane == i ? code : codes;
+			}
 		}
-		if (prefix < 14u + (suffix_len ? 1u : 0u)) {
-			/* the usual shape: prefix zeros, a one, suffix_len bits,
-			 * all inside the 32 bits at hand */
-			uint32_t suffix = ((bits << (prefix + 1u)) >> 1) >>
-					  (31u - suffix_len);
-			code = (prefix << suffix_len) + suffix;
-			wb_skip(wb, prefix + 1u + suffix_len);
-		} else {
-			err |= bits < (1u << 6) ? 1u : 0u; /* level_prefix > 25 */
-			wb_skip(wb, prefix + 1u);
-			code = (prefix < 15u ? prefix : 15u) << suffix_len;
-			uint32_t size = prefix == 14u ? 4u : prefix - 3u;
-			code += wb_u(wb, lane, size);
-			if (prefix >= 15 && suffix_len == 0)
-				code += 15;
-			if (prefix >= 16)
-				code += (1u << (prefix - 3u)) - 4096u;
-		}
-		code += first_adj;
-		sd_level_finish(code, suffix_len, lv, i, lane);
 		i++;
-	}
-first_done:
-	for (; i < tc; i++) {
-		uint32_t bits = wb_peek(wb, lane);
-		uint32_t prefix = (uint32_t)__builtin_clz(bits | 0x3fu);
-		if (prefix < 15u) {
-			/* the usual shape with 1 <= suffix_len <= 6.  levelCode =
-			 * (prefix << suffix_len) + suffix lies below 3 << suffix_len
-			 * exactly when prefix < 3, so suffix_len grows iff prefix >= 3
-			 * -- no magnitude needed on the scalar side */
-			/* the n = prefix + 1 + suffix_len bits of the code word end in
-			 * "1 suffix": x = 2^suffix_len + suffix, and
-			 * (prefix << suffix_len) + suffix = ((prefix - 1) << suffix_len) + x */
-			const uint32_t n = prefix + 1u + suffix_len;
-			uint32_t cv = ((prefix - 1u) << suffix_len) + (bits >> (32u - n));
-			wb_skip(wb, n);
-			asm("" : "+v"(cv));
-			uint32_t ng = cv & 1u;
-			uint32_t vv = ((((cv + 2u) >> 1) ^ (0u - ng)) + ng) & 0xffffu;
-			lv = lane == i ? vv : lv;
-			/* (suffix_len never exceeds 6: add-with-carry and a minimum) */
-			uint32_t grown = suffix_len + (prefix >= 3u ? 1u : 0u);
-			suffix_len = grown < 6u ? grown : 6u;
-		} else {
-			err |= bits < (1u << 6) ? 1u : 0u; /* level_prefix > 25 */
-			wb_skip(wb, prefix + 1u);
-			uint32_t code = 15u << suffix_len;
-			code += wb_u(wb, lane, prefix - 3u);
-			if (prefix >= 16)
-				code += (1u << (prefix - 3u)) - 4096u;
-			sd_level_finish(code, suffix_len, lv, i, lane);
+		/* every later level finds 1 <= suffixLength <= 6 and no adjustment:
+		 * levelCode lies below 3 << suffixLength exactly when prefix < 3, so
+		 * suffixLength grows iff prefix >= 3 -- no magnitude needed */
+		for (; i < tc; i++) {
+			vb_norm(vb, wb);
+			uint32_t b1 = vb_peek(vb);
+			uint32_t p = (uint32_t)__builtin_clz(b1 | 0x10000u);
+			if (vb_true(p >= 15u)) {
+				uint32_t ssl = (uint32_t)__builtin_amdgcn_readfirstlane(
+					(int)sl);
+				vb_store(vb, wb);
+				uint32_t code = sd_level_escape(wb, lane, ssl, 0u, serr);
+				vb_load(vb, wb);
+				sl = ssl;
+				VB_VREG(sl);
+				VB_VREG(code);
+				codes = lane == i ? code : codes;
+			} else {
+				uint32_t n = p + 1u + sl;
+				uint32_t code = ((p - 1u) << sl) + (b1 >> (32u - n));
+				vb_skip(vb, n); /* <= 21 bits */
+				codes = lane == i ? code : codes;
+				uint32_t grown = sl + (p >= 3u ? 1u : 0u);
+				sl = grown < 6u ? grown : 6u;
+			}
 		}
 	}
+	/* ---- total_zeros and the runs: zl = zerosLeft before run i, per lane ---- */
+	uint32_t zl = 0;
 	uint32_t zeros_left = 0;
-	if (tc < maxnum)
-		err |= vlc_total_zeros(vt, wb, lane, tc, maxnum, zeros_left);
+	if (tc < maxnum) {
+		vb_norm(vb, wb);
+		uint32_t b1 = vb_peek(vb);
+		/* 1 <= tc < maxnum and maxnum in {4, 8, 15, 16} (the callers' block
+		 * constants) keep k inside the 25 tables */
+		uint32_t k = maxnum == 4 ? 14u + tc : maxnum == 8 ? 17u + tc : tc - 1u;
+		uint32_t bad;
+		int hit;
+		uint32_t cw = vlc_match(vt.tz + 128u * k, vt.off16, b1, bad, hit);
+		uint32_t okm = bad - 1u;
+		serr |= bad;
+		vb_skip(vb, cw & 31u & okm); /* <= 9 bits */
+		zeros_left = (uint32_t)hit & okm;
+	}
 	for (i = 0; i + 1 < tc && zeros_left > 0; i++) {
-		uint32_t run;
+		/* run_before (Table 9-10).  zerosLeft <= 6: at most 3 bits, a byte
+		 * table per class held by lane `class` (vt.rb_lo / rb_hi), entry =
+		 * len << 4 | run picked by the next three bits; zerosLeft > 6: three
+		 * bits (111 .. 001 -> 0 .. 6) or a unary tail (0001 -> 7, ...) */
 		zl = wb_setlane(zl, i, zeros_left, lane);
+		vb_norm(vb, wb);
+		uint32_t b1 = vb_peek(vb);
+		uint32_t top3 = b1 >> 29;
 		if (zeros_left > 6) {
-			err |= vlc_run_before(vt, wb, lane, zeros_left, run);
-			uint32_t over = run > zeros_left ? 1u : 0u;
-			err |= over;
-			zeros_left -= over ? zeros_left : run;
+			uint32_t t3 = (uint32_t)__builtin_amdgcn_readfirstlane((int)top3);
+			if (t3) {
+				vb_skip(vb, 3);
+				zeros_left -= 7u - t3;
+			} else {
+				uint32_t sb = (uint32_t)__builtin_amdgcn_readfirstlane(
+					(int)b1);
+				uint32_t lz = (uint32_t)__builtin_clz(sb | 0x00100000u);
+				uint32_t bad = (sb >> 21) == 0 ? 1u : 0u; /* > 11 bits */
+				uint32_t run = bad ? 0u : lz + 4u;
+				uint32_t over = run > zeros_left ? 1u : 0u;
+				serr |= bad | over;
+				vb_skip(vb, bad ? 0u : lz + 1u);
+				zeros_left -= over ? zeros_left : run;
+			}
 		} else {
-			/* Table 9-10 for zerosLeft <= 6 only has runs up to
-			 * zerosLeft and a code word for every 3-bit pattern:
-			 * nothing to check */
-			vlc_run_before(vt, wb, lane, zeros_left, run);
-			zeros_left -= run;
+			/* byte top3 of the lane's eight (selector 0x0c: zero) */
+			uint32_t ev = __builtin_amdgcn_perm(vt.rb_hi, vt.rb_lo,
+							    top3 | 0x0c0c0c00u);
+			uint32_t e = (uint32_t)__builtin_amdgcn_readlane((int)ev,
+									 (int)zeros_left);
+			vb_skip(vb, e >> 4);
+			zeros_left -= e & 15u;
 		}
 	}
 	zl = wb_setlane(zl, tc - 1u, zeros_left, lane);
-	/* lane i places coefficient i */
+	/* ---- levelCode -> value (even code -> +(code + 2) / 2, odd ->
+	 * -(code + 1) / 2, as int16), and lane i places coefficient i ---- */
+	uint32_t ng = codes & 1u;
+	uint32_t lv = ((((codes + 2u) >> 1) ^ (0u - ng)) + ng) & 0xffffu;
 	uint32_t pos = zl + tc - 1u - lane;
 	bool mine = lane < tc;
 	/* malformed: outside the block (Appendix C.5) */
 	bool outside = mine && pos >= maxnum;
-	err |= __ballot(outside) != 0 ? 1u : 0u;
+	verr |= outside ? 1u : 0u;
 	*reinterpret_cast<uint16_t *>(
 		lds_sel(stage + H264_AMD_T2_HEAD + 2u * (coef_off + pos),
 			stage - SD_DUMP_BYTES, mine && !outside, lane)) = (uint16_t)lv;
-	return err;
+	return tc;
 }
 
 /* checksum terms of 8 consecutive 16-bit words starting at word index idx */
@@ -987,6 +1042,20 @@ sd_slice_data(WaveBits &wb, const VlcTabs &vt, uint32_t cbp_map, uint32_t lane,
 	const bool chroma12 = cat == 1 || cat == 2;
 	const uint32_t nchroma = cat == 1 ? 4u : 8u; /* 4x4 blocks per component */
 	bool ok = true;
+	VBits vb;
+	vb_load(vb, wb);
+#define VRD_UE(var)                                                            \
+	do {                                                                   \
+		var = vb_ue(vb, wb, ok);                                       \
+		if (!ok)                                                       \
+			return -EIO;                                           \
+	} while (0)
+#define VRD_SE(var)                                                            \
+	do {                                                                   \
+		var = vb_se(vb, wb, ok);                                       \
+		if (!ok)                                                       \
+			return -EIO;                                           \
+	} while (0)
 	MbCtx m;
 	m.cur = m.left = m.sum = 0;
 	m.availA = m.availB = 0;
@@ -1007,15 +1076,18 @@ sd_slice_data(WaveBits &wb, const VlcTabs &vt, uint32_t cbp_map, uint32_t lane,
 	asm volatile("" : "+v"(v_field));
 
 	do {
-		wb_sync(wb, lane);
+		/* the scalar cursor is in step with vb here (vb_store at the end of
+		 * the previous macroblock / vb_load above) */
+		vb_sync(vb, wb, lane);
 		if (wb_overrun(wb))
 			return -EIO;
 		if (!is_i) {
 			uint32_t run;
-			RD_UE(run);
+			VRD_UE(run);
 			/* a run read across the end of the data (zero padding) is
 			 * the reference's -EIO on the ue itself: no skipped
 			 * macroblock may come out of it */
+			vb_store(vb, wb);
 			if (wb_overrun(wb))
 				return -EIO;
 			for (uint32_t r = 0; r < run; r++) {
@@ -1048,7 +1120,7 @@ sd_slice_data(WaveBits &wb, const VlcTabs &vt, uint32_t cbp_map, uint32_t lane,
 		uint32_t pm0 = PM_I4x4, pm1 = PM_I4x4;
 		uint32_t i16pred = 0, cbp_luma = 0, cbp_chroma = 0;
 		bool intra = is_i; /* decode t with the I-slice table */
-		RD_UE(raw_type);
+		VRD_UE(raw_type);
 		t = raw_type;
 		if (is_si) {
 			if (t == 0) {
@@ -1122,6 +1194,7 @@ sd_slice_data(WaveBits &wb, const VlcTabs &vt, uint32_t cbp_map, uint32_t lane,
 
 		if (mb_type == H264_MB_TYPE_I_PCM) {
 			/* pcm_alignment_zero_bit, then raw samples (:622-645) */
+			vb_store(vb, wb);
 			uint32_t p = wb_pos(wb) & 7u;
 			if (p && wb_u(wb, lane, 8u - p) != 0)
 				return -EIO;
@@ -1148,6 +1221,8 @@ sd_slice_data(WaveBits &wb, const VlcTabs &vt, uint32_t cbp_map, uint32_t lane,
 					(uint16_t)smp;
 				wb_skip(wb, 64u * bd);
 			}
+			wb_sync(wb, lane);
+			vb_load(vb, wb);
 			m.cur = lane < 48 ? 16u : 0u;
 		} else {
 			bool no_sub8 = true;
@@ -1158,7 +1233,7 @@ sd_slice_data(WaveBits &wb, const VlcTabs &vt, uint32_t cbp_map, uint32_t lane,
 #pragma unroll
 				for (uint32_t p = 0; p < 4; p++) {
 					uint32_t st;
-					RD_UE(st);
+					VRD_UE(st);
 					pred_lo |= (st & 0xffu) << (8u * p);
 					if (is_b) {
 						if (st >= 13)
@@ -1190,7 +1265,7 @@ sd_slice_data(WaveBits &wb, const VlcTabs &vt, uint32_t cbp_map, uint32_t lane,
 					for (uint32_t p = 0; p < 4; p++)
 						if (sub_pm[p] != PM_DIRECT &&
 						    sub_pm[p] != PM_L1) {
-							uint32_t r = wb_te(wb, lane, S.nref0, ok);
+							uint32_t r = vb_te(vb, wb, S.nref0, ok);
 							if (!ok)
 								return -EIO;
 							lds_w8(stage, 64 + p, r, lane);
@@ -1201,7 +1276,7 @@ sd_slice_data(WaveBits &wb, const VlcTabs &vt, uint32_t cbp_map, uint32_t lane,
 					for (uint32_t p = 0; p < 4; p++)
 						if (sub_pm[p] != PM_DIRECT &&
 						    sub_pm[p] != PM_L0) {
-							uint32_t r = wb_te(wb, lane, S.nref1, ok);
+							uint32_t r = vb_te(vb, wb, S.nref1, ok);
 							if (!ok)
 								return -EIO;
 							lds_w8(stage, 68 + p, r, lane);
@@ -1214,11 +1289,11 @@ sd_slice_data(WaveBits &wb, const VlcTabs &vt, uint32_t cbp_map, uint32_t lane,
 						if (sub_pm[p] == PM_DIRECT ||
 						    sub_pm[p] == (l ? PM_L0 : PM_L1))
 							continue;
-						wb_sync(wb, lane);
+						vb_sync(vb, wb, lane);
 						for (uint32_t s = 0; s < sub_n[p]; s++)
 							for (uint32_t c = 0; c < 2; c++) {
 								int32_t d;
-								RD_SE(d);
+								VRD_SE(d);
 								lds_w16(stage,
 									128 + 64 * l + 16 * p + 4 * s + 2 * c,
 									(uint32_t)d, lane);
@@ -1228,7 +1303,7 @@ sd_slice_data(WaveBits &wb, const VlcTabs &vt, uint32_t cbp_map, uint32_t lane,
 			} else {
 				/* ---- mb_pred (:506-601) ---- */
 				if (S.t8x8_mode && mb_type == H264_MB_TYPE_I_NxN) {
-					if (wb_u1(wb, lane)) {
+					if (vb_u(vb, wb, 1)) {
 						flags |= H264_AMD_MB_TRANSFORM_8X8;
 						pm0 = PM_I8x8;
 					}
@@ -1236,16 +1311,20 @@ sd_slice_data(WaveBits &wb, const VlcTabs &vt, uint32_t cbp_map, uint32_t lane,
 				if (pm0 == PM_I4x4 || pm0 == PM_I8x8 || pm0 == PM_I16x16) {
 					if (pm0 != PM_I16x16) {
 						uint32_t n = pm0 == PM_I4x4 ? 16u : 4u;
-						wb_skip(wb, sd_intra_pred_modes(wb, lane, n,
-										stage));
+						vb_norm(vb, wb);
+						vb_skip(vb, sd_intra_pred_modes(vb, wb, lane,
+										n, stage));
+						/* up to 64 bits: two steps */
+						vb_norm(vb, wb);
+						vb_norm(vb, wb);
 					}
 					if (chroma12)
-						RD_UE(icp);
+						VRD_UE(icp);
 				} else if (pm0 != PM_DIRECT) {
 					if (S.nref0 > 0) {
 						for (uint32_t p = 0; p < nparts; p++)
 							if ((p ? pm1 : pm0) != PM_L1) {
-								uint32_t r = wb_te(wb, lane, S.nref0, ok);
+								uint32_t r = vb_te(vb, wb, S.nref0, ok);
 								if (!ok)
 									return -EIO;
 								lds_w8(stage, 64 + p, r, lane);
@@ -1254,7 +1333,7 @@ sd_slice_data(WaveBits &wb, const VlcTabs &vt, uint32_t cbp_map, uint32_t lane,
 					if (S.nref1 > 0) {
 						for (uint32_t p = 0; p < nparts; p++)
 							if ((p ? pm1 : pm0) != PM_L0) {
-								uint32_t r = wb_te(wb, lane, S.nref1, ok);
+								uint32_t r = vb_te(vb, wb, S.nref1, ok);
 								if (!ok)
 									return -EIO;
 								lds_w8(stage, 68 + p, r, lane);
@@ -1266,21 +1345,21 @@ sd_slice_data(WaveBits &wb, const VlcTabs &vt, uint32_t cbp_map, uint32_t lane,
 								continue;
 							for (uint32_t c = 0; c < 2; c++) {
 								int32_t d;
-								RD_SE(d);
+								VRD_SE(d);
 								lds_w16(stage, 128 + 64 * l + 16 * p + 2 * c,
 									(uint32_t)d, lane);
 							}
 						}
 				}
 			}
-			wb_sync(wb, lane);
+			vb_sync(vb, wb, lane);
 			if (pm0 != PM_I16x16) {
 				/* coded_block_pattern, me(v) mapping of Table 9-4
 				 * (src/h264_slice_data.c:1041-1080); cbp_map lane =
 				 * codeNum, bytes: cat 1/2 intra, inter, cat 0/3
 				 * intra, inter */
 				uint32_t code;
-				RD_UE(code);
+				VRD_UE(code);
 				if (cat > 3 || code >= (chroma12 ? 48u : 16u))
 					return -EIO;
 				bool intra_col = mb_type == H264_MB_TYPE_I_NxN ||
@@ -1296,12 +1375,12 @@ sd_slice_data(WaveBits &wb, const VlcTabs &vt, uint32_t cbp_map, uint32_t lane,
 				    mb_type != H264_MB_TYPE_I_NxN && no_sub8 &&
 				    (mb_type != H264_MB_TYPE_B_Direct_16x16 ||
 				     S.direct8x8)) {
-					if (wb_u1(wb, lane))
+					if (vb_u(vb, wb, 1))
 						flags |= H264_AMD_MB_TRANSFORM_8X8;
 				}
 			}
 			if (cbp_luma > 0 || cbp_chroma > 0 || pm0 == PM_I16x16) {
-				RD_SE(qpd);
+				VRD_SE(qpd);
 				/* ---- residual (:334-419).  The coded blocks
 				 * are the set bits of `todo` (bit = step, in
 				 * bitstream order); blocks that are not coded cost
@@ -1325,9 +1404,10 @@ sd_slice_data(WaveBits &wb, const VlcTabs &vt, uint32_t cbp_map, uint32_t lane,
 					todo |= c << 17;
 				}
 				const uint32_t vinfo = i16 ? m.info_i16 : m.info_n;
-				uint32_t err = 0;
+				uint32_t serr = 0, verr = 0;
 				while (todo) {
-					wb_sync(wb, lane);
+					vb_sync(vb, wb, lane);
+					vb_norm(vb, wb);
 					/* Runs of empty blocks.  For nC < 8 the code word
 					 * for "no coefficient" is a string of 1, 2 or 4
 					 * one bits (Table 9-5: nC < 2, < 4, < 8), and an
@@ -1340,8 +1420,8 @@ sd_slice_data(WaveBits &wb, const VlcTabs &vt, uint32_t cbp_map, uint32_t lane,
 					 * run at once.  A block with a non-zero nz slot
 					 * (a parked DC count), nC >= 8 or a chroma DC
 					 * block ends the run. */
-					uint32_t peek = wb_peek(wb, lane);
-					if ((int32_t)peek < 0) {
+					uint32_t peek = vb_peek(vb);
+					if (vb_true((int32_t)peek < 0)) {
 						uint32_t ncv = sd_nc_all(m);
 						uint32_t lb = ncv < 2u ? 1u : ncv < 4u ? 2u
 							      : ncv < 8u ? 4u : 64u;
@@ -1359,7 +1439,8 @@ sd_slice_data(WaveBits &wb, const VlcTabs &vt, uint32_t cbp_map, uint32_t lane,
 						if (fit) {
 							uint32_t last = 63u - (uint32_t)
 								__builtin_clzll(fit);
-							wb_skip(wb, (uint32_t)
+							/* <= 31 bits */
+							vb_skip(vb, (uint32_t)
 								__builtin_amdgcn_readlane(
 									(int)incl, (int)last));
 							todo &= ~fit;
@@ -1371,22 +1452,22 @@ sd_slice_data(WaveBits &wb, const VlcTabs &vt, uint32_t cbp_map, uint32_t lane,
 					uint32_t info = (uint32_t)__builtin_amdgcn_readlane(
 						(int)vinfo, (int)step);
 					uint32_t nzlane = info & 63u;
-					uint32_t tc;
 					uint32_t cls = (uint32_t)__builtin_amdgcn_readlane(
 						(int)sd_class_all(m, lane, cat),
 						(int)(info >> 24));
-					err |= sd_residual_block(
-						wb, vt, lane, stage, cls, peek,
+					uint32_t tc = sd_residual_block(
+						vb, wb, vt, lane, stage, cls, peek,
 						(info >> 6) & 31u,
-						(info >> 13) & 0x7ffu, tc);
+						(info >> 13) & 0x7ffu, serr, verr);
 					/* TotalCoeff is recorded for every class, DC
 					 * blocks included (Appendix C.4) */
 					sd_nz_set(m, nzlane, tc, lane);
 				}
-				if (err)
+				if (serr || vb_true(verr != 0))
 					return -EIO;
 			}
 		}
+		vb_store(vb, wb);
 		if (wb_overrun(wb))
 			return -EIO;
 
@@ -1411,6 +1492,8 @@ sd_slice_data(WaveBits &wb, const VlcTabs &vt, uint32_t cbp_map, uint32_t lane,
 		mbidx++;
 		mb_count = mbidx;
 	} while (wb_more_rbsp_data(wb, lane));
+#undef VRD_UE
+#undef VRD_SE
 	return 0;
 }
 
