@@ -167,11 +167,21 @@ static void vlc_build_tables(dev_vlc_tables *t)
 #undef H264_TZ_C420
 #undef H264_TZ_C422
 #undef H264_CBP
-	/* entries without a code word repeat entry 0 of their table: the decoder
-	 * takes the lowest matching entry, so a duplicate never wins */
-	for (int c = 0; c < DEV_VLC_CT_CLASSES; c++)
-		for (uint32_t l = next[c]; l < 64; l++)
-			t->ct[c][l] = t->ct[c][0];
+	/* coeff_token rows end in catch-all entries (mask 0: every bit string
+	 * matches; the decoder takes the LOWEST matching entry, so they only win
+	 * when no code word does): length 0, no coefficients, DEV_VLC_BAD set --
+	 * a malformed token needs no "nothing matched" case in the kernel.  Every
+	 * class leaves room: 62 code words with nC, 14 / 30 for chroma DC */
+	for (int c = 0; c < DEV_VLC_CT_CLASSES; c++) {
+		if (next[c] > 63)
+			abort();
+		for (uint32_t l = next[c]; l < 64; l++) {
+			t->ct[c][l].mask = 0;
+			t->ct[c][l].cw = DEV_VLC_BAD;
+		}
+	}
+	/* total_zeros tables can be full (16 values): entries without a code
+	 * word repeat entry 0, a duplicate never wins */
 	for (int k = 0; k < DEV_VLC_TZ_TABLES; k++)
 		for (uint32_t l = tz_n[k]; l < 16; l++)
 			t->tz[k][l] = t->tz[k][0];

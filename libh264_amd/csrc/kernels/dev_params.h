@@ -74,6 +74,7 @@ struct dev_epoch {
 struct dev_vlc_entry {
 	uint32_t mask, cw;
 };
+#define DEV_VLC_BAD 0x8000u /* payload bit of a coeff_token catch-all entry */
 #define DEV_VLC_CT_CLASSES 6 /* nC<2, <4, <8, >=8 (FLC), chroma DC 420, 422 */
 #define DEV_VLC_TZ_TABLES 25 /* 4x4 tzVlcIndex 1..15, 2x2 1..3, 2x4 1..7 */
 struct dev_vlc_tables {

@@ -606,15 +606,6 @@ __device__ __forceinline__ uint32_t sd_nc(const MbCtx &m, uint32_t l)
 	return (uint32_t)__builtin_amdgcn_readlane((int)sd_nc_all(m), (int)l);
 }
 
-/* coeff_token table class of every block, per lane (vector unit); lanes 48 / 49
- * hold the constant classes of the chroma DC blocks (3 + ChromaArrayType) */
-__device__ __forceinline__ uint32_t sd_class_all(const MbCtx &m, uint32_t lane,
-						 uint32_t cat)
-{
-	uint32_t c = vlc_ct_class(sd_nc_all(m));
-	return lane >= 48u ? 3u + cat : c;
-}
-
 /* block at lane l now has TotalCoeff tc (it may have had another value: the
  * DC blocks park theirs at index 0, Appendix C.4) */
 __device__ __forceinline__ void sd_nz_set(MbCtx &m, uint32_t l, uint32_t tc,
@@ -764,11 +755,10 @@ sd_residual_block(VBits &vb, WaveBits &wb, const VlcTabs &vt, uint32_t lane,
 	 * already has ---- */
 	uint32_t tc, t1, len;
 	{
-		uint32_t bad;
-		int hit;
-		uint32_t cw = vlc_match(vt.ct + 512u * cls, vt.off64, bits, bad, hit);
-		cw &= bad - 1u; /* everything 0 on a bad code */
-		serr |= bad;
+		/* a malformed token comes back as "no coefficients, length 0" with
+		 * DEV_VLC_BAD set */
+		uint32_t cw = vlc_match_total(vt.ct + 512u * cls, vt.off64, bits);
+		serr |= cw & DEV_VLC_BAD;
 		len = cw & 31u;
 		t1 = (cw >> 5) & 3u;
 		tc = (cw >> 7) & 31u;
@@ -791,8 +781,11 @@ sd_residual_block(VBits &vb, WaveBits &wb, const VlcTabs &vt, uint32_t lane,
 		/* ---- levels (9.2.2.1).  The FIRST one in full generality:
 		 * suffixLength 0 or 1, and after fewer than three trailing ones it
 		 * cannot be +-1, so its code is offset by 2 ---- */
-		const uint32_t first_adj = t1 < 3 ? 2u : 0u;
-		const uint32_t sl0 = (tc > 10 && t1 < 3) ? 1u : 0u;
+		/* plain integer arithmetic: booleans would live in 64-bit lane
+		 * masks and come back through the vector unit */
+		const uint32_t few = (t1 - 3u) >> 31; /* t1 < 3 */
+		const uint32_t first_adj = 2u * few;
+		const uint32_t sl0 = few & ((10u - tc) >> 31); /* && tc > 10 */
 		uint32_t sl; /* suffixLength, vector side */
 		vb_norm(vb, wb);
 		{
@@ -828,27 +821,40 @@ sd_residual_block(VBits &vb, WaveBits &wb, const VlcTabs &vt, uint32_t lane,
 		/* every later level finds 1 <= suffixLength <= 6 and no adjustment:
 		 * levelCode lies below 3 << suffixLength exactly when prefix < 3, so
 		 * suffixLength grows iff prefix >= 3 -- no magnitude needed */
+		/* Window: a level takes at most 21 bits here, so the loop keeps
+		 * vo <= 43 (64 - 21) at its top.  ONE test per level covers both
+		 * rare events, the escape (prefix >= 15) and the window step: the
+		 * usual updates are applied first and an escape takes them back. */
+		vb_norm(vb, wb);
 		for (; i < tc; i++) {
-			vb_norm(vb, wb);
+			const uint32_t vo0 = vb.vo, sl_in = sl;
 			uint32_t b1 = vb_peek(vb);
 			uint32_t p = (uint32_t)__builtin_clz(b1 | 0x10000u);
-			if (vb_true(p >= 15u)) {
-				uint32_t ssl = (uint32_t)__builtin_amdgcn_readfirstlane(
-					(int)sl);
-				vb_store(vb, wb);
-				uint32_t code = sd_level_escape(wb, lane, ssl, 0u, serr);
-				vb_load(vb, wb);
-				sl = ssl;
-				VB_VREG(sl);
-				VB_VREG(code);
-				codes = lane == i ? code : codes;
-			} else {
-				uint32_t n = p + 1u + sl;
-				uint32_t code = ((p - 1u) << sl) + (b1 >> (32u - n));
-				vb_skip(vb, n); /* <= 21 bits */
-				codes = lane == i ? code : codes;
-				uint32_t grown = sl + (p >= 3u ? 1u : 0u);
-				sl = grown < 6u ? grown : 6u;
+			uint32_t n = p + 1u + sl;
+			uint32_t code = ((p - 1u) << sl) + (b1 >> (32u - n));
+			vb_skip(vb, n); /* <= 21 bits */
+			uint32_t keep = codes;
+			codes = lane == i ? code : codes;
+			uint32_t grown = sl + (p >= 3u ? 1u : 0u);
+			sl = grown < 6u ? grown : 6u;
+			/* p >= 15  <=>  p + 29 >= 44;  vo >= 44: step */
+			uint32_t rare = p + 29u > vb.vo ? p + 29u : vb.vo;
+			if (vb_true(rare >= 44u)) {
+				if (vb_true(p >= 15u)) {
+					uint32_t ssl = (uint32_t)
+						__builtin_amdgcn_readfirstlane((int)sl_in);
+					vb.vo = vo0;
+					vb_store(vb, wb);
+					uint32_t c2 = sd_level_escape(wb, lane, ssl, 0u,
+								      serr);
+					vb_load(vb, wb);
+					sl = ssl;
+					VB_VREG(sl);
+					VB_VREG(c2);
+					codes = lane == i ? c2 : keep;
+				} else {
+					vb_norm(vb, wb);
+				}
 			}
 		}
 	}
@@ -869,23 +875,22 @@ sd_residual_block(VBits &vb, WaveBits &wb, const VlcTabs &vt, uint32_t lane,
 		vb_skip(vb, cw & 31u & okm); /* <= 9 bits */
 		zeros_left = (uint32_t)hit & okm;
 	}
-	for (i = 0; i + 1 < tc && zeros_left > 0; i++) {
-		/* run_before (Table 9-10).  zerosLeft <= 6: at most 3 bits, a byte
-		 * table per class held by lane `class` (vt.rb_lo / rb_hi), entry =
-		 * len << 4 | run picked by the next three bits; zerosLeft > 6: three
-		 * bits (111 .. 001 -> 0 .. 6) or a unary tail (0001 -> 7, ...) */
-		zl = wb_setlane(zl, i, zeros_left, lane);
+	/* run_before (Table 9-10).  zerosLeft > 6: three bits (111 .. 001 -> 0 ..
+	 * 6) or a unary tail (0001 -> 7, ...), up to 11 bits, one at a time.
+	 * zerosLeft <= 6: at most 3 bits, so ten of them fit behind one vb_norm();
+	 * a byte table per class held by lane `class` (vt.rb_lo / rb_hi), entry =
+	 * len << 4 | run picked by the next three bits. */
+	i = 0;
+	while (i + 1 < tc && zeros_left > 0) {
 		vb_norm(vb, wb);
-		uint32_t b1 = vb_peek(vb);
-		uint32_t top3 = b1 >> 29;
 		if (zeros_left > 6) {
-			uint32_t t3 = (uint32_t)__builtin_amdgcn_readfirstlane((int)top3);
+			zl = wb_setlane(zl, i, zeros_left, lane);
+			uint32_t sb = vb_peek_s(vb);
+			uint32_t t3 = sb >> 29;
 			if (t3) {
 				vb_skip(vb, 3);
 				zeros_left -= 7u - t3;
 			} else {
-				uint32_t sb = (uint32_t)__builtin_amdgcn_readfirstlane(
-					(int)b1);
 				uint32_t lz = (uint32_t)__builtin_clz(sb | 0x00100000u);
 				uint32_t bad = (sb >> 21) == 0 ? 1u : 0u; /* > 11 bits */
 				uint32_t run = bad ? 0u : lz + 4u;
@@ -894,15 +899,22 @@ sd_residual_block(VBits &vb, WaveBits &wb, const VlcTabs &vt, uint32_t lane,
 				vb_skip(vb, bad ? 0u : lz + 1u);
 				zeros_left -= over ? zeros_left : run;
 			}
-		} else {
+			i++;
+			continue;
+		}
+		uint32_t lim = tc - 1u < i + 10u ? tc - 1u : i + 10u;
+		do {
+			zl = wb_setlane(zl, i, zeros_left, lane);
+			uint32_t top3 = vb_peek(vb) >> 29;
 			/* byte top3 of the lane's eight (selector 0x0c: zero) */
 			uint32_t ev = __builtin_amdgcn_perm(vt.rb_hi, vt.rb_lo,
 							    top3 | 0x0c0c0c00u);
-			uint32_t e = (uint32_t)__builtin_amdgcn_readlane((int)ev,
-									 (int)zeros_left);
-			vb_skip(vb, e >> 4);
+			uint32_t e = (uint32_t)__builtin_amdgcn_readlane(
+				(int)ev, (int)zeros_left);
+			vb_skip(vb, e >> 4); /* <= 3 bits */
 			zeros_left -= e & 15u;
-		}
+			i++;
+		} while (i < lim && zeros_left > 0);
 	}
 	zl = wb_setlane(zl, tc - 1u, zeros_left, lane);
 	/* ---- levelCode -> value (even code -> +(code + 2) / 2, odd ->
@@ -1448,13 +1460,15 @@ sd_slice_data(WaveBits &wb, const VlcTabs &vt, uint32_t cbp_map, uint32_t lane,
 						}
 					}
 					uint32_t step = (uint32_t)__builtin_ctzll(todo);
-					todo &= todo - 1ull;
+					asm("s_bitset0_b64 %0, %1" : "+s"(todo) : "s"(step));
 					uint32_t info = (uint32_t)__builtin_amdgcn_readlane(
 						(int)vinfo, (int)step);
 					uint32_t nzlane = info & 63u;
-					uint32_t cls = (uint32_t)__builtin_amdgcn_readlane(
-						(int)sd_class_all(m, lane, cat),
-						(int)(info >> 24));
+					/* table class from nC of the block's context
+					 * lane (scalar side: the vector port is the
+					 * fuller one); chroma DC blocks have their own */
+					uint32_t cls = vlc_ct_class(sd_nc(m, info >> 24));
+					cls = ((info >> 11) & 3u) ? 3u + cat : cls;
 					uint32_t tc = sd_residual_block(
 						vb, wb, vt, lane, stage, cls, peek,
 						(info >> 6) & 31u,

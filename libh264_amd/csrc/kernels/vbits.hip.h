@@ -98,7 +98,11 @@ __device__ __forceinline__ void vb_sync(VBits &b, WaveBits &s, uint32_t lane)
 /* next 32 bits, MSB first, in every lane */
 __device__ __forceinline__ uint32_t vb_peek(const VBits &b)
 {
-	return (uint32_t)((b.W << b.vo) >> 32);
+	uint32_t r = (uint32_t)((b.W << b.vo) >> 32);
+	/* opaque: tests of the result stay 32-bit compares instead of being
+	 * folded into 64-bit compares of the shifted pair */
+	asm volatile("" : "+v"(r));
+	return r;
 }
 
 /* the same as a scalar */

@@ -20,7 +20,9 @@
  *                  k = tzVlcIndex - 1 for 4x4 blocks, 14 + tzVlcIndex for
  *                  chroma DC 2x2, 17 + tzVlcIndex for chroma DC 2x4;
  *                  payload = len
- * Entries without a code word repeat entry 0 of their table.
+ * coeff_token rows end in catch-all entries (payload DEV_VLC_BAD): something
+ * always matches.  total_zeros entries without a code word repeat entry 0 of
+ * their table.
  * run_before (Table 9-10) is decoded in closed form, see vlc_run_before().
  */
 #ifndef H264_AMD_VLC_LANES_HIP_H
@@ -91,33 +93,22 @@ __device__ __forceinline__ uint32_t vlc_match(const uint8_t *row, uint32_t off,
 	return (uint32_t)__builtin_amdgcn_readlane((int)e.y, hit & 63);
 }
 
+/* the same for a row that ends in catch-all entries: something always matches */
+__device__ __forceinline__ uint32_t vlc_match_total(const uint8_t *row,
+						    uint32_t off, uint32_t bits)
+{
+	const uint2 e = *reinterpret_cast<const uint2 *>(row + off);
+	wb_mask_t m = __ballot(((bits ^ e.y) & e.x) == 0u);
+	/* m != 0: the catch-all entries */
+	return (uint32_t)__builtin_amdgcn_readlane((int)e.y, __builtin_ctzll(m));
+}
+
 /* class of coeff_token table for nC = 0..8+: 0 0 1 1 2 2 2 2 3, two bits each
  * (works on scalars and per lane alike) */
 __device__ __forceinline__ uint32_t vlc_ct_class(uint32_t nC)
 {
 	uint32_t c = nC < 8u ? nC : 8u;
 	return (0x3AA50u >> (2u * c)) & 3u;
-}
-
-/* coeff_token with the table class `cls` (0..3 by nC, 4 / 5 chroma DC 4:2:0 /
- * 4:2:2).  Returns the bad flag. */
-__device__ __forceinline__ uint32_t vlc_coeff_token(const VlcTabs &t, WaveBits &s,
-						    uint32_t lane, uint32_t cls,
-						    uint32_t bits, uint32_t &t1,
-						    uint32_t &tc, uint32_t &rest)
-{
-	/* bits: the peek at the cursor, which the caller already has */
-	uint32_t bad;
-	int hit;
-	uint32_t cw = vlc_match(t.ct + 512u * cls, t.off64, bits, bad, hit);
-	cw &= bad - 1u; /* everything 0 on a bad code */
-	wb_skip(s, cw & 31u);
-	t1 = (cw >> 5) & 3u;
-	tc = (cw >> 7) & 31u;
-	/* what the peek holds behind the token (at least 16 bits): the
-	 * trailing-one signs need no second peek */
-	rest = bits << (cw & 31u);
-	return bad;
 }
 
 /* total_zeros; maxnum selects the table family (4: chroma DC 2x2, 8: chroma

@@ -1,0 +1,74 @@
+#!/usr/bin/env python3
+"""Instruction mix of the decode kernel per macroblock from rocprofv3 PMC
+passes (run on the GPU box):
+
+    python tools/pmc_decode.py [--slices 1024] [--lib path/to/libengine_x.so]
+
+Runs `rocprofv3 --kernel-trace --pmc ...` over tools/ab_decode.py (one batch of
+bench slices, two launches) once per counter group and prints, per counter, the
+value per macroblock summed over the chip.  SQ counters count per wave
+instruction; one macroblock = one wave's work, so "per macroblock" is also "per
+wave and macroblock"."""
+import argparse
+import csv
+import glob
+import json
+import os
+import subprocess
+import sys
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+GROUPS = [
+    ["SQ_INSTS_SALU", "SQ_INSTS_VALU", "SQ_INSTS_LDS", "SQ_INSTS_BRANCH",
+     "SQ_INSTS_SMEM", "SQ_INSTS_VMEM_RD", "SQ_INSTS_VMEM_WR", "SQ_WAVES"],
+    ["SQ_WAVE_CYCLES", "SQ_WAIT_ANY", "SQ_WAIT_INST_ANY", "SQ_ACTIVE_INST_ANY",
+     "SQ_ACTIVE_INST_SCA", "SQ_ACTIVE_INST_VALU", "SQ_ACTIVE_INST_LDS",
+     "SQ_BUSY_CYCLES"],
+]
+KERNEL = "h264_amd_k_decode_slices"
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--slices", type=int, default=1024)
+    ap.add_argument("--lib", default="")
+    ap.add_argument("--out", default="/tmp/pmc_decode")
+    args = ap.parse_args()
+    env = dict(os.environ, TMPDIR="/tmp")
+    if args.lib:
+        env["H264_AMD_ENGINE_LIB"] = os.path.abspath(args.lib)
+    res = {}
+    for gi, grp in enumerate(GROUPS):
+        d = "%s_%d" % (args.out, gi)
+        subprocess.run(["rm", "-rf", d])
+        cmd = ["rocprofv3", "--kernel-trace", "--pmc"] + grp + \
+            ["--output-format", "csv", "-d", d, "--", sys.executable,
+             os.path.join(ROOT, "tools", "ab_decode.py"), "--child",
+             "--slices", str(args.slices), "--steps", "1"]
+        p = subprocess.run(cmd, cwd="/tmp", env=env, stdout=subprocess.PIPE,
+                           stderr=subprocess.STDOUT, text=True)
+        if p.returncode != 0:
+            print(p.stdout[-2000:])
+            raise SystemExit("rocprofv3 failed")
+        n = {}
+        for f in glob.glob(os.path.join(d, "**", "*counter_collection.csv"),
+                           recursive=True):
+            for row in csv.DictReader(open(f)):
+                if not row["Kernel_Name"].startswith(KERNEL):
+                    continue
+                c = row["Counter_Name"]
+                res[c] = res.get(c, 0.0) + float(row["Counter_Value"])
+                n[c] = n.get(c, 0) + 1
+        for c in grp:
+            if c in res and n.get(c):
+                res[c] /= n[c]  # per launch
+    mbs = 8160.0 * args.slices
+    out = {"slices": args.slices, "lib": os.path.basename(args.lib) or
+           "in-tree"}
+    for c, v in res.items():
+        out[c + "_per_mb"] = round(v / mbs, 2)
+    print(json.dumps(out))
+
+
+if __name__ == "__main__":
+    main()
