@@ -10,20 +10,35 @@ records and the per-slice checksum over the full macroblock syntax written
 back.  Inputs are resident in HBM before the timed region.
 
   python bench.py [--gpus N] [--steps K] [--warmup W] [--slices S]
+                  [--workload c2|c4] [--no-extras]
 
-N > 1: one process per GPU (torch.distributed, backend nccl = RCCL), the batch
-is sharded by slice with no data-path collective (slices are independent,
-SURVEY.md 8(e)); weak scaling: every rank decodes S slices.  value = bits of
-all ranks / max-over-ranks time.
+N > 1: one process per GPU (torch.distributed, backend nccl = RCCL).  Started
+without a launcher (`python bench.py --gpus 8`) this process starts the N ranks
+itself with torch.distributed.run -- before anything touches a GPU -- and
+returns their exit code; under a launcher (WORLD_SIZE set) --gpus must agree
+with it.
+  c2 (default): the batch is sharded by slice with no data-path collective
+      (slices are independent); weak scaling: every rank
+      decodes S slices.  value = bits of all ranks / max-over-ranks time.
+  c4: BASELINE config 4 -- ONE mixed Annex-B byte stream held by rank 0 goes
+      through scan -> plan -> broadcast of the parameter sets -> RCCL
+      point-to-point scatter of the slice bytes -> decode on every rank ->
+      all-gather of the result records (libh264_amd/pipeline.py); strong
+      scaling.
 
 Prints ONE JSON line (rank 0).  roofline.achieved = slice bytes read per launch
-/ average kernel time from HIP events on the launch stream; cpu_baseline = the
-oracle's reader (kind "port") on a bounded sample, all host cores.
+/ median kernel time from HIP events on the launch stream; cpu_baseline = the
+oracle's reader (kind "port") on a bounded sample, all host cores.  With one
+GPU the default run also times the other configurations' kernels (scan on
+1 GiB, write-back of the batch, synthetic CABAC slices encode / subset decode,
+the config-4 pipeline on 64 MiB) and reports them under "side" next to the
+measured streaming-read ceiling of the box.
 """
 import argparse
 import ctypes as C
 import json
 import os
+import subprocess
 import sys
 import time
 
@@ -62,131 +77,310 @@ def make_workload(n_slices, seed0, threads):
             np.concatenate(sizes))
 
 
-def run_c4(args, eng, dist, rank, world, cores):
-    """BASELINE config 4: a mixed Annex-B byte stream resident in HBM goes
-    through the whole device-side pipeline per step -- scan, NAL heads to the
-    host, parameter sets parsed by the drop-in library's host code, slice
-    descriptors built, every slice decoded in one launch.  N > 1: every rank
-    has its own stream (weak scaling, no data-path collective)."""
-    import libh264_amd
-    from libh264_amd import Params, shard
-    from libh264_amd.ctypes_abi import Sps, Pps, TIER_T0
+def spawn_ranks(args):
+    """`python bench.py --gpus N` without a launcher: start the N ranks.  This
+    process has not imported torch or touched HIP (a process that has must not
+    be replaced, and the children need the GPUs to themselves)."""
+    port = os.environ.get("MASTER_PORT") or str(29500 + os.getpid() % 400)
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1",
+           "--nproc-per-node", str(args.gpus), "--master-addr", "127.0.0.1",
+           "--master-port", port, os.path.abspath(__file__)] + sys.argv[1:]
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    return subprocess.call(cmd, env=env)
+
+
+def rate(nbytes, ms, ceiling_gbs):
+    gbs = nbytes / ms / 1e6
+    return {"achieved_GBps": round(gbs, 1),
+            "frac_nominal": round(gbs / HBM_PEAK_GBS, 4),
+            "frac_measured": round(gbs / ceiling_gbs, 4) if ceiling_gbs else
+            None}
+
+
+def side_measurements(eng, params, d_buf, descs, d_descs, sizes, buf, offs,
+                      order, cores, reps):
+    """The other configurations' kernels, timed with HIP events on the engine's
+    stream (median of `reps`), each checked on a sample (BASELINE configs 3, 4,
+    5).  Runs after the headline's timed region."""
     sys.path.insert(0, os.path.join(ROOT, "tools"))
     import bench_kernels
-    H = C.CDLL(os.path.join(ROOT, "libh264_amd", "lib", "libh264.so"))
-    H.h264_parse_sps.argtypes = [C.c_char_p, C.c_size_t, C.POINTER(Sps)]
-    H.h264_parse_pps.argtypes = [C.c_char_p, C.c_size_t, C.POINTER(Sps),
-                                 C.POINTER(Pps)]
-    t0 = time.time()
-    data = bench_kernels.mixed_stream(args.mib << 20, cores,
-                                      seed0=shard.rank_seed(rank))
-    gen_s = time.time() - t0
-    d_buf = eng.upload(np.frombuffer(data + b"\xff" * 64, dtype=np.uint8))
-    cap = len(data) // 4096 + 1024
+    import orc
+    from libh264_amd import pipeline
+    from libh264_amd.ctypes_abi import (Sps, Pps, SliceHeader, TIER_NONE,
+                                        TIER_T0)
+    import streams
+    side = {}
+    n = len(descs)
+    total = int(sizes.sum())
 
-    def step(out=None):
-        tab, count, consumed, d_nals = eng.scan(d_buf, len(data), cap,
-                                                keep=True)
-        heads = eng.gather_nal_heads(d_buf, d_nals, count, 64)
-        d_nals.free()
-        params = Params()
-        sps = Sps()
-        descs = []
-        for i in range(count):
-            t = int(heads[i, 0]) & 0x1f
-            if t not in (1, 5, 7, 8):
-                continue
-            a, b = int(tab[i, 0]), int(tab[i, 1])
-            if t in (7, 8):
-                raw = heads[i, :b - a].tobytes() if b - a <= 64 else \
-                    eng.download(d_buf, b - a, offset=a).tobytes()
-                if t == 7:
-                    sps = Sps()
-                    if H.h264_parse_sps(raw, len(raw), C.byref(sps)) == 0:
-                        params.put_sps(sps)
-                else:
-                    pps = Pps()
-                    if H.h264_parse_pps(raw, len(raw), C.byref(sps),
-                                        C.byref(pps)) == 0:
-                        params.put_pps(pps)
-            else:
-                descs.append((a, b - a, params.epoch))
-        out = eng.decode_slices(params, d_buf, descs, reader_flags=1,
-                                tier=TIER_T0, mb_capacity=8160, outputs=out)
-        return tab, count, consumed, descs, out, params
+    # ---- read ceiling + scan on 1 GiB (the 64 MiB config-4 stream laid out
+    # sixteen times; every copy ends in the stream's last NAL unit, so the
+    # whole GiB is one legal stream) ----
+    data = bench_kernels.mixed_stream(64 << 20, cores, seed0=5)
+    unit = np.frombuffer(data, dtype=np.uint8)
+    unit = np.concatenate([unit, np.zeros((-len(unit)) % 16, dtype=np.uint8)])
+    reps_gib = max(1, (1 << 30) // len(unit))
+    d_big = eng.alloc(reps_gib * len(unit) + 64)
+    d_unit = eng.upload(unit)
+    for k in range(reps_gib):
+        eng.copy_d2d(d_big, k * len(unit), d_unit, 0, len(unit))
+    big_len = reps_gib * len(unit)
+    ceil_ms = float(np.median([eng.probe_read_ms(d_big, big_len)
+                               for _ in range(reps)]))
+    ceiling = big_len / ceil_ms / 1e6
+    side["read_ceiling"] = {
+        "kernel": "h264_amd_k_probe_read (pure streaming read, the scan's "
+                  "work mapping)", "bytes": big_len,
+        "ms": round(ceil_ms, 4), "GBps": round(ceiling, 1),
+        "frac_nominal": round(ceiling / HBM_PEAK_GBS, 4)}
+    cap = big_len // 4096 + 1024
+    _t1, count1, _c1 = eng.scan(d_unit, len(unit), cap)
+    tab, count, consumed = eng.scan(d_big, big_len, cap)
+    ms, ms_all = [], []
+    for _ in range(reps):
+        eng.scan(d_big, big_len, cap)
+        ms.append(eng.last_kernel_ms("scan"))
+        ms_all.append(eng.last_kernel_ms("scan_all"))
+    ref = orc.parse_stream(data[:2 << 20], flags=0, want=0)
+    nref = len(ref.nals) - 1  # the prefix cuts its last NAL unit short
+    if [(int(a), int(b)) for a, b in tab[:nref]] != \
+            [(x.start, x.end) for x in ref.nals[:nref]] or \
+            count != reps_gib * count1:
+        raise SystemExit("scan parity failure")
+    k_ms = float(np.median(ms))
+    side["scan_1gib"] = dict(
+        kernel="h264_amd_k_scan_mark", nal_units=int(count),
+        bytes=big_len, ms=round(k_ms, 4),
+        mark_prefix_place_ms=round(float(np.median(ms_all)), 4),
+        **rate(big_len, k_ms, ceiling))
+    del d_big
 
-    tab, count, consumed, descs, out, params = step()
-    for _ in range(args.warmup):
-        step(out)
-    eng.sync()
-    if dist is not None:
-        dist.barrier()
-    k_dec, k_scan = [], []
+    # ---- config 4 on the 64 MiB stream, one GPU: the pipeline's stages ----
+    class Ops(pipeline.EngineOpsPlain):
+        pass
+    ops = Ops(eng)
+    stream = eng.upload(np.concatenate(
+        [np.frombuffer(data, dtype=np.uint8), np.full(64, 0xff, np.uint8)]))
+    pipeline.run_step(None, ops, stream, len(data), len(data) // 4096 + 1024)
+    walls, kms = [], []
+    for _ in range(max(3, reps // 2)):
+        t0 = time.perf_counter()
+        table, plan = pipeline.run_step(None, ops, stream, len(data),
+                                        len(data) // 4096 + 1024)
+        eng.sync()
+        walls.append(time.perf_counter() - t0)
+        kms.append(ops.last_decode_ms)
+    res = table.view(np.dtype(
+        [("status", "<i4"), ("flags", "<u4"), ("x", "u1", 56)]))
+    mbc = table[:, 24:28].copy().view("<u4").ravel()
+    if (res["status"] != 0).any() or (mbc != 8160).any() or \
+            plan.consumed != len(data):
+        raise SystemExit("C4 pipeline failed")
+    w_ms = 1e3 * float(np.median(walls))
+    side["c4_64mib"] = {
+        "workload": "%.1f MiB mixed Annex-B stream: scan -> NAL heads -> host "
+                    "parameter sets -> one decode launch (%d slices = %.1f of "
+                    "16 wave slots per CU)" % (len(data) / 2 ** 20,
+                                               len(plan.descs),
+                                               len(plan.descs) / 256.0),
+        "ms_per_step": round(w_ms, 3),
+        "decode_kernel_ms": round(float(np.median(kms)), 3),
+        "mbit_per_s": round(8e-3 * len(data) / w_ms, 1),
+        "macroblocks_per_s": round(8160e3 * len(plan.descs) / w_ms, 1)}
+    del stream
+
+    # ---- config 5: write-back of the whole batch, byte-identical ----
+    out = eng.decode_slices(params, d_buf, descs, reader_flags=0,
+                            tier=TIER_NONE, want_headers=True, d_descs=d_descs)
+    capn = int(sizes.max()) + 64
+    d_out, ooffs, osizes = eng.write_slices(params, d_buf, out, capn)
+    if not (osizes == descs["size"].astype(np.int32)).all():
+        raise SystemExit("write-back: sizes differ")
+    for k in range(0, n, max(1, n // 16)):
+        got = eng.download(d_out, int(osizes[k]), offset=int(ooffs[k]))
+        i = int(order[k])
+        if not np.array_equal(got, buf[int(offs[i]):int(offs[i]) +
+                                      int(sizes[i])]):
+            raise SystemExit("write-back: slice %d differs" % i)
+    ms = []
+    for _ in range(reps):
+        eng.write_slices(params, d_buf, out, capn, fetch=False, d_out=d_out)
+        ms.append(eng.last_kernel_ms("write"))
+    k_ms = float(np.median(ms))
+    side["write_back"] = dict(
+        kernel="h264_amd_k_write_slices", slices=n,
+        bytes_read_plus_written=2 * total, ms=round(k_ms, 4),
+        byte_identical_sample=16, **rate(2 * total, k_ms, ceiling))
+    del d_out, out
+
+    # ---- config 3: CABAC P-slices (what the reference's writers emit) ----
+    sps, pps = Sps(), Pps()
+    sps.profile_idc, sps.level_idc, sps.chroma_format_idc = 100, 40, 1
+    sps.pic_order_cnt_type, sps.max_num_ref_frames = 2, 1
+    sps.pic_width_in_mbs_minus1, sps.pic_height_in_map_units_minus1 = 119, 67
+    sps.frame_mbs_only_flag = sps.direct_8x8_inference_flag = 1
+    pps.entropy_coding_mode_flag = 1
+    pps.deblocking_filter_control_present_flag = 1
+    pps.transform_8x8_mode_flag = 1
+    from libh264_amd import Params
+    cparams = Params()
+    cparams.put_sps(sps)
+    cepoch = cparams.put_pps(pps)
+    descs3, hdrs3 = [], []
+    for k in range(n):
+        sh = SliceHeader()
+        sh.slice_type = 5
+        sh.frame_num = k % 16
+        sh.slice_qp_delta = (k % 21) - 10
+        sh.cabac_init_idc = k % 3
+        descs3.append((1, cepoch, 8160, 2, 1))
+        hdrs3.append(sh)
+    got = eng.encode_synth(cparams, descs3, hdrs3, 1 << 10)
+    bld = orc.Builder()
+    for k in range(0, n, max(1, n // 8)):
+        if got[k] != bld.nalu(2, 1, sps=sps, pps=pps, sh=hdrs3[k], kind=2,
+                              mb_count=8160):
+            raise SystemExit("synthetic slice %d differs from the oracle" % k)
+    ms = []
+    for _ in range(max(2, reps // 3)):
+        eng.encode_synth(cparams, descs3, hdrs3, 1 << 10)
+        ms.append(eng.last_kernel_ms("synth"))
+    k_ms = float(np.median(ms))
+    side["cabac_encode"] = {
+        "kernel": "h264_amd_k_encode_synth", "slices": n,
+        "workload": "all-skip CABAC P-slices of 8160 macroblocks "
+                    "(h264_write_skipped_p_slice)",
+        "ms": round(k_ms, 4),
+        "macroblocks_per_s": round(8160e3 * n / k_ms, 1),
+        "bytes_out": int(sum(len(g) for g in got))}
+    buf3, offs3, sizes3 = streams.pack_nals(got)
+    d3 = eng.upload(buf3)
+    dd = [(int(o), int(s), cepoch) for o, s in zip(offs3, sizes3)]
+    out4 = eng.decode_slices(cparams, d3, dd, reader_flags=0x101, tier=TIER_T0,
+                             mb_capacity=8160, want_headers=True)
+    r4 = eng.fetch_results(out4)
+    if not all(r4[k].status == 0 and r4[k].mb_count == 8160
+               for k in range(n)):
+        raise SystemExit("CABAC subset decode failed")
+    ref = orc.parse_nalus([bld.nalu(3, 7, sps=sps),
+                           bld.nalu(3, 8, sps=sps, pps=pps)] +
+                          [got[k] for k in range(0, n, max(1, n // 8))],
+                          flags=0x101, want=0)
+    for j, k in enumerate(range(0, n, max(1, n // 8))):
+        if ref.results[j].checksum != r4[k].checksum:
+            raise SystemExit("CABAC subset decode: checksum of slice %d" % k)
+    ms = []
+    for _ in range(reps):
+        eng.decode_slices(cparams, d3, dd, reader_flags=0x101, tier=TIER_T0,
+                          mb_capacity=8160, want_headers=True, outputs=out4)
+        ms.append(eng.last_kernel_ms("cabac"))
+    k_ms = float(np.median(ms))
+    side["cabac_subset_decode"] = {
+        "kernel": "h264_amd_k_decode_cabac_subset", "slices": n,
+        "workload": "the same slices, every mb_skip_flag / end_of_slice bin "
+                    "arithmetic-decoded, T0 records (extension: the reference "
+                    "has no CABAC decoder)",
+        "ms": round(k_ms, 4),
+        "macroblocks_per_s": round(8160e3 * n / k_ms, 1),
+        "bins_per_s": round(2 * 8160e3 * n / k_ms, 1)}
+    return side
+
+
+def run_c4(args, dist, rank, world, local_rank, cores):
+    """BASELINE config 4, strong scaling: rank 0 holds the stream."""
+    import libh264_amd  # noqa: F401
+    from libh264_amd import pipeline, shard
+    sys.path.insert(0, os.path.join(ROOT, "tools"))
+    import bench_kernels
+    share = bool(os.environ.get("H264_AMD_REHEARSE_ONE_GPU"))
+    ops = pipeline.EngineOps(0 if share else local_rank, host_staging=share)
+    data, stream, gen_s = None, None, 0.0
+    if rank == 0:
+        t0 = time.time()
+        data = bench_kernels.mixed_stream(args.mib << 20, cores, seed0=17)
+        gen_s = time.time() - t0
+        stream = ops.upload(np.frombuffer(data, dtype=np.uint8))
+    length = len(data) if rank == 0 else 0
+    cap = (args.mib << 20) // 4096 + 1024
+
+    def barrier():
+        ops.sync()
+        if dist is not None:
+            dist.barrier()
+
+    for _ in range(max(1, args.warmup)):
+        table, plan = pipeline.run_step(dist, ops, stream, length, cap)
+    barrier()
+    timing, kms = {}, []
     t_start = time.perf_counter()
     for _ in range(args.steps):
-        step(out)
-        k_dec.append(eng.last_kernel_ms("decode"))
-        k_scan.append(eng.last_kernel_ms("scan_all"))
-    eng.sync()
-    if dist is not None:
-        dist.barrier()
+        table, plan = pipeline.run_step(dist, ops, stream, length, cap,
+                                        timing=timing)
+        kms.append(getattr(ops, "last_decode_ms", 0.0))
+    barrier()
     elapsed = shard.max_over_ranks(dist, time.perf_counter() - t_start,
-                                   device="cuda")
-    res = eng.fetch_results(out)
-    n = len(descs)
-    bad = [i for i in range(n) if res[i].status != 0 or res[i].mb_count != 8160]
-    if bad or consumed != len(data):
-        raise SystemExit("rank %d: C4 pipeline failed (%d bad slices, consumed "
-                         "%d of %d)" % (rank, len(bad), consumed, len(data)))
-    verified = 0
+                                   device=ops.device)
+    k_ms = shard.max_over_ranks(dist, float(np.median(kms)) if kms else 0.0,
+                                device=ops.device)
+    n = len(plan.descs)
+    mbc = table[:, 24:28].copy().view("<u4").ravel()
+    status = table[:, 0:4].copy().view("<i4").ravel()
+    if (status != 0).any() or (mbc != 8160).any():
+        raise SystemExit("rank %d: C4 pipeline failed (%d bad slices)" %
+                         (rank, int((status != 0).sum())))
     if rank == 0:
         import orc
-        head = [data[int(tab[i, 0]):int(tab[i, 1])] for i in range(count)
-                if int(data[int(tab[i, 0])]) & 0x1f in (7, 8)][:2]
+        from libh264_amd.ctypes_abi import SliceResult
+        if plan.consumed != len(data):
+            raise SystemExit("scan consumed %d of %d" % (plan.consumed,
+                                                         len(data)))
+        head = [raw for _k, raw in plan.ps_nals[:2]]
+        verified = 0
         for k in range(0, n, max(1, n // max(1, args.verify))):
-            a, sz, _ = descs[k]
+            a, sz = int(plan.descs["offset"][k]), int(plan.descs["size"][k])
             r = orc.parse_nalus(head + [data[a:a + sz]], want=0).results[0]
-            g = res[k]
+            g = SliceResult.from_buffer_copy(table[k].tobytes())
             if (r.status, r.mb_count, r.checksum, r.end_bit) != \
                     (g.status, g.mb_count, g.checksum, g.end_bit):
                 raise SystemExit("parity failure on slice %d" % k)
             verified += 1
-    slice_bytes = sum(d[1] for d in descs)
-    all_bytes, all_mbs = shard.sum_over_ranks(
-        dist, [len(data), 8160 * n], device="cuda")
-    if rank == 0:
-        dec_ms, scan_ms = float(np.mean(k_dec)), float(np.mean(k_scan))
+        slice_bytes = int(plan.descs["size"].sum())
+        ms_step = 1e3 * elapsed / args.steps
+        per = max(1, -(-n // world))
         print(json.dumps({
             "metric": "bitstream_parsed_mbit_per_s",
-            "value": round(8.0 * all_bytes * args.steps / elapsed / 1e6, 1),
+            "value": round(8.0 * len(data) * args.steps / elapsed / 1e6, 1),
             "unit": "Mbit/s", "n_gpus": world, "steps": args.steps,
-            "warmup": args.warmup,
-            "ms_per_step": round(1e3 * elapsed / args.steps, 3),
-            "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
-            "dtype": "u8", "data": "synthetic",
-            "macroblocks_per_s": round(all_mbs * args.steps / elapsed, 1),
+            "warmup": args.warmup, "ms_per_step": round(ms_step, 3),
+            "higher_is_better": True, "scaling": "strong",
+            "vs_baseline": None, "dtype": "u8", "data": "synthetic",
+            "macroblocks_per_s": round(8160.0 * n * args.steps / elapsed, 1),
+            "kernel_only_mbit_per_s": round(8e-3 * slice_bytes / k_ms, 1)
+            if k_ms else None,
             "config": {
-                "workload": "C4: %.1f MiB mixed Annex-B stream per GPU (%d NAL "
-                            "units, %d 1080p I/P slices): scan -> NAL heads -> "
-                            "host parameter sets -> one decode launch" %
-                            (len(data) / 2 ** 20, count, n),
-                "parallelism": "one stream per GPU, %d GPU(s), no data-path "
-                               "collective" % world},
+                "workload": "C4: one %.1f MiB mixed Annex-B stream on rank 0 "
+                            "(%d NAL units, %d 1080p I/P slices): scan -> plan "
+                            "-> broadcast -> point-to-point scatter of slice "
+                            "bytes -> decode on every rank -> all-gather of "
+                            "the result records" % (len(data) / 2 ** 20,
+                                                    plan.n_nals, n),
+                "parallelism": "slices of one stream size-balanced over %d "
+                               "GPU(s); RCCL send/recv scatter + all-gather" %
+                               world},
+            "stage_ms_per_step": {k: round(1e3 * v / args.steps, 3)
+                                  for k, v in timing.items()},
             "roofline": {
                 "bound": "hbm", "kernel": "h264_amd_k_decode_slices",
-                "achieved": round(slice_bytes / dec_ms / 1e6, 2),
+                "achieved": round(slice_bytes / world / k_ms / 1e6, 2)
+                if k_ms else None,
                 "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                "frac": round(slice_bytes / dec_ms / 1e6 / HBM_PEAK_GBS, 5),
-                "traffic": None, "kernel_ms": round(dec_ms, 3),
-                "note": ("%d slices fill %.1f of 16 wave slots per CU: the "
-                         "step is bound by the ~58 ms one wavefront needs for "
-                         "one 1080p slice" % (n, n / 256.0)) if n < 4096 else
-                        ("%d slices = %.1f rounds of 16 waves per CU; CAVLC is "
-                         "a serial chain per slice: latency / scalar-issue "
-                         "bound, not HBM bound" % (n, n / 4096.0))},
-            "scan": {"kernels": "mark + prefix + place",
-                     "ms": round(scan_ms, 4),
-                     "achieved_GBps": round(len(data) / scan_ms / 1e6, 1)},
+                "frac": round(slice_bytes / world / k_ms / 1e6 / HBM_PEAK_GBS,
+                              5) if k_ms else None,
+                "traffic": None, "kernel_ms": round(k_ms, 3),
+                "note": "%d slices per GPU fill %.1f of 16 wave slots per CU: "
+                        "a step is bound by the time one wavefront needs for "
+                        "one 1080p slice" % (per, per / 256.0)},
             "cpu_baseline": None,
             "verified_slices_vs_oracle": verified,
             "gen_seconds": round(gen_s, 1)}), flush=True)
@@ -196,10 +390,10 @@ def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--workload", default="c2", choices=["c2", "c4"],
                     help="c2: batch of I-slices (BASELINE config 2, the "
-                         "headline); c4: mixed Annex-B stream through scan + "
-                         "decode (config 4)")
+                         "headline); c4: one mixed Annex-B stream through scan "
+                         "+ scatter + decode + gather (config 4)")
     ap.add_argument("--mib", type=int, default=64,
-                    help="c4: stream size per GPU in MiB")
+                    help="c4: stream size in MiB")
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=5)
     ap.add_argument("--warmup", type=int, default=2)
@@ -210,34 +404,33 @@ def main():
                     help="slices re-parsed by the oracle after the run")
     ap.add_argument("--cpu-sample", type=int, default=0,
                     help="slices in the CPU baseline sample (0 = auto)")
+    ap.add_argument("--no-extras", action="store_true",
+                    help="skip the side measurements of the one-GPU run")
     args = ap.parse_args()
+    if args.gpus < 1:
+        raise SystemExit("--gpus must be at least 1")
 
-    world = int(os.environ.get("WORLD_SIZE", "1"))
-    rank = int(os.environ.get("RANK", "0"))
-    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    # ORDER MATTERS: torch ships its own ROCm runtime (same soname as the
-    # system one the engine was linked against).  With torch initialised
-    # first the engine library resolves to that already-loaded copy and the
-    # process has ONE HIP runtime; the other way round torch finds no GPU
-    # (measured, tools/dist_probe.py).  libh264_amd loads its library lazily.
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        sys.exit(spawn_ranks(args))
+
+    from libh264_amd import shard
+    rank, world, local_rank = shard.rank_env(gpus=args.gpus)
     dist = None
+    share = bool(os.environ.get("H264_AMD_REHEARSE_ONE_GPU"))
     if world > 1 or os.environ.get("H264_AMD_FORCE_DIST"):
-        # H264_AMD_FORCE_DIST: rehearse the N > 1 path on a one-GPU box
-        import torch
-        import torch.distributed as dist_mod
-        dist = dist_mod
-        torch.cuda.set_device(local_rank)
-        if "MASTER_ADDR" not in os.environ:
-            os.environ["MASTER_ADDR"] = "127.0.0.1"
-            os.environ.setdefault("MASTER_PORT", "29573")
-            os.environ.setdefault("RANK", "0")
-            os.environ.setdefault("WORLD_SIZE", "1")
-        dist.init_process_group(backend="nccl",
-                                device_id=torch.device("cuda", local_rank))
+        # torch.distributed (RCCL) first, the engine library afterwards: see
+        # shard.init_dist.  Rehearsals on a one-GPU box: H264_AMD_FORCE_DIST=1
+        # runs the N > 1 code with one rank over RCCL;
+        # H264_AMD_REHEARSE_ONE_GPU=1 lets N ranks share GPU 0 (RCCL refuses
+        # two ranks on one device, so that mode talks gloo through the host)
+        dist = shard.init_dist("gloo" if share else "nccl",
+                               0 if share else local_rank)
+    if share:
+        local_rank = 0
     n_gpus = world
 
     import libh264_amd
-    from libh264_amd import gen, Params, shard
+    from libh264_amd import gen, Params
 
     from libh264_amd.ctypes_abi import Sps, Pps, TIER_NONE, TIER_T0, TIER_T1
 
@@ -250,8 +443,7 @@ def main():
     cores = max(1, min(avail, int(os.environ.get("H264_AMD_HOST_CORES", "16"))))
     threads = cores
     if args.workload == "c4":
-        eng = libh264_amd.Engine(local_rank)
-        run_c4(args, eng, dist, rank, world, cores)
+        run_c4(args, dist, rank, world, local_rank, cores)
         if dist is not None:
             dist.destroy_process_group()
         return
@@ -317,7 +509,8 @@ def main():
         kernel_ms.append(eng.last_kernel_ms("decode"))
     barrier()
     elapsed = time.perf_counter() - t_start
-    elapsed = shard.max_over_ranks(dist, elapsed, device="cuda")
+    coll_dev = "cpu" if share else "cuda"
+    elapsed = shard.max_over_ranks(dist, elapsed, device=coll_dev)
 
     res = eng.fetch_results(out)
     bad = [i for i in range(args.slices)
@@ -332,6 +525,7 @@ def main():
     # checksum over every macroblock's full syntax (checker only, not timed)
     verified = 0
     cpu = None
+    side = None
     if rank == 0:
         import orc
         for j in range(min(args.verify, args.slices)):
@@ -387,12 +581,16 @@ def main():
                     "mb_per_s": round(m1.value / s1.value, 1),
                     "sample": "%d slices, %.1f s" % (n_1, s1.value)},
             }
+            if not args.no_extras and dist is None:
+                side = side_measurements(eng, params, d_buf, descs, d_descs,
+                                         sizes, buf, offs, order, cores,
+                                         reps=max(5, min(args.steps, 20)))
 
     ms_per_step = 1e3 * elapsed / args.steps
     all_bytes, all_mbs = shard.sum_over_ranks(dist, [total_bytes, total_mbs],
-                                              device="cuda")
+                                              device=coll_dev)
     mbit_s = 8.0 * all_bytes * args.steps / elapsed / 1e6
-    k_ms = float(np.mean(kernel_ms))
+    k_ms = float(np.median(kernel_ms))  # median
     achieved = total_bytes / (k_ms * 1e-3) / 1e9
     out_bytes = args.slices * (64 + 8160 * out["stride"])
 
@@ -416,6 +614,7 @@ def main():
         traffic = None
 
     if rank == 0:
+        ceiling = side["read_ceiling"]["GBps"] if side else None
         line = {
             "metric": "bitstream_parsed_mbit_per_s",
             "value": round(mbit_s, 1),
@@ -448,9 +647,12 @@ def main():
                 "peak": HBM_PEAK_GBS,
                 "unit": "GB/s",
                 "frac": round(achieved / HBM_PEAK_GBS, 5),
+                "frac_measured_read_ceiling": round(achieved / ceiling, 5)
+                if ceiling else None,
                 "traffic": traffic,
                 "traffic_source": traffic_src,
                 "kernel_ms": round(k_ms, 3),
+                "kernel_ms_stat": "median of %d launches" % len(kernel_ms),
                 "algorithmic_bytes_read": total_bytes,
                 "algorithmic_bytes_written": out_bytes,
                 # a serial-dependency kernel is described by
@@ -462,12 +664,16 @@ def main():
                     (k_ms * 1e-3 * 2.4e9 / max(1.0, args.slices / 4096.0)), 5),
                 "clock_ghz_assumed": 2.4,
                 "note": "CAVLC is a serial dependency chain per slice: the "
-                        "kernel is latency bound, not HBM bound",
+                        "kernel is bound by instruction issue (scalar and "
+                        "vector ports of four waves per SIMD), not by HBM",
             },
             "cpu_baseline": cpu,
             "verified_slices_vs_oracle": verified,
             "gen_seconds": round(gen_s, 1),
+            "build_id": libh264_amd.build_id()[:16],
         }
+        if side:
+            line["side"] = side
         print(json.dumps(line), flush=True)
     if dist is not None:
         dist.destroy_process_group()

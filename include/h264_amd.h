@@ -223,6 +223,9 @@ H264_API int h264_amd_download(struct h264_amd_engine *eng,
 			       void *dst,
 			       const void *d_src,
 			       size_t size);
+/* device to device, on the engine's stream */
+H264_API int h264_amd_copy(struct h264_amd_engine *e, void *d_dst,
+			   const void *d_src, size_t size);
 H264_API int h264_amd_memset(struct h264_amd_engine *eng,
 			     void *d_dst,
 			     int value,
@@ -399,6 +402,19 @@ H264_API int h264_amd_cabac_init_states(struct h264_amd_engine *eng,
 H264_API int h264_amd_last_kernel_ms(struct h264_amd_engine *eng,
 				     const char *family,
 				     float *ms);
+
+/* ---- calibration and identification ---------------------------------------- */
+
+/* Time one pure streaming read of d_buf[0 .. len) with the scan kernel's work
+ * mapping (HIP events on the engine's stream): the measured read ceiling of
+ * the box, next to which the HBM-bound kernels' rates are reported. */
+H264_API int h264_amd_probe_read(struct h264_amd_engine *e, const uint8_t *d_buf,
+				 size_t len, float *ms);
+
+/* Identity of the sources this library was built from (hex sha256 over
+ * libh264_amd/csrc and include, see libh264_amd/build.py), "unidentified" for
+ * a build made by hand. */
+H264_API const char *h264_amd_build_id(void);
 
 #ifdef __cplusplus
 }

@@ -8,7 +8,8 @@ the thin Python host mirror used by the tests and by bench.py: ctypes bindings
 gfx950 device the engine calls raise.
 """
 from . import ctypes_abi  # noqa: F401
-from .capi import Engine, Params, EngineError, engine_lib, available  # noqa: F401
+from .capi import (Engine, Params, EngineError, engine_lib, available,  # noqa: F401
+                   build_id)
 from . import gen  # noqa: F401
 
 __all__ = ["Engine", "Params", "EngineError", "engine_lib", "available", "gen",

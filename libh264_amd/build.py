@@ -48,6 +48,32 @@ def _tree(*dirs):
     return out
 
 
+def source_id():
+    """sha256 over every source file the engine and the drop-in library are
+    built from (path-sorted, names included): h264_amd_build_id() of a library
+    built from this tree returns it."""
+    import hashlib
+    h = hashlib.sha256()
+    for f in sorted(_tree(CSRC, INC)):
+        h.update(os.path.relpath(f, ROOT).encode() + b"\0")
+        with open(f, "rb") as fh:
+            h.update(fh.read())
+    return h.hexdigest()
+
+
+def built_id(lib_path):
+    """h264_amd_build_id() of a built library, read without loading it into
+    this process (the string sits in .rodata behind a marker)."""
+    with open(lib_path, "rb") as fh:
+        blob = fh.read()
+    tag = b"h264_amd_build_id="
+    i = blob.find(tag)
+    if i < 0:
+        return None
+    j = blob.find(b"\0", i)
+    return blob[i + len(tag):j].decode()
+
+
 def _run(cmd):
     print("+", " ".join(cmd), file=sys.stderr)
     subprocess.check_call(cmd)
@@ -65,7 +91,8 @@ def build_gen(force=False):
 def build_engine(force=False):
     out = os.path.join(LIB, "libh264_amd_engine.so")
     srcs = _tree(CSRC, INC)
-    if force or _newer(out, srcs):
+    sid = source_id()
+    if force or _newer(out, srcs) or built_id(out) != sid:
         # -structurizecfg-skip-uniform-regions: the decode kernel's control
         # flow is wave-uniform by construction; without the flag the backend
         # still threads uniform regions through the structurizer's flow blocks
@@ -76,6 +103,7 @@ def build_engine(force=False):
             "-O3 -mllvm -structurizecfg-skip-uniform-regions").split()
         _run([_hipcc(), "--offload-arch=gfx950"] + opt + ["-std=c++17", "-fPIC",
               "-shared", "-Wno-unused-value", "-I" + INC, "-I" + CSRC,
+              '-DH264_AMD_BUILD_ID="%s"' % sid,
               os.path.join(CSRC, "engine.hip"), "-o", out])
     return out
 
@@ -91,7 +119,8 @@ def build_host(force=False):
     if not csrcs:
         return None
     srcs = _tree(hostdir, INC)
-    if force or _newer(out, srcs + [build_engine()]):
+    sid = source_id()
+    if force or _newer(out, srcs + [build_engine()]) or built_id(out) != sid:
         objs = []
         objdir = os.path.join(LIB, "obj")
         os.makedirs(objdir, exist_ok=True)
@@ -99,6 +128,7 @@ def build_host(force=False):
             o = os.path.join(objdir, os.path.basename(c)[:-2] + ".o")
             _run(["gcc", "-std=gnu99", "-D_GNU_SOURCE", "-DH264_API_EXPORTS",
                   "-fvisibility=hidden", "-O2", "-fPIC", "-Wall",
+                  '-DH264_AMD_BUILD_ID="%s"' % sid,
                   "-I" + INC, "-I" + CSRC, "-c", c, "-o", o])
             objs.append(o)
         _run(["gcc", "-shared", "-o", out] + objs +

@@ -48,6 +48,7 @@ def engine_lib():
     L.h264_amd_upload.argtypes = [vp, vp, vp, sz]
     L.h264_amd_download.argtypes = [vp, vp, vp, sz]
     L.h264_amd_memset.argtypes = [vp, vp, C.c_int, sz]
+    L.h264_amd_copy.argtypes = [vp, vp, vp, sz]
     L.h264_amd_last_kernel_ms.argtypes = [vp, C.c_char_p,
                                           C.POINTER(C.c_float)]
     L.h264_amd_params_new.argtypes = [C.POINTER(vp)]
@@ -64,8 +65,15 @@ def engine_lib():
     L.h264_amd_write_slices.argtypes = [vp, vp, C.POINTER(WriteArgs)]
     L.h264_amd_encode_synth_slices.argtypes = [vp, vp, C.POINTER(SynthArgs)]
     L.h264_amd_cabac_init_states.argtypes = [vp, vp, u32, vp]
+    L.h264_amd_probe_read.argtypes = [vp, vp, sz, C.POINTER(C.c_float)]
+    L.h264_amd_build_id.restype = C.c_char_p
     _LIB = L
     return L
+
+
+def build_id():
+    """identity of the sources the loaded engine library was built from"""
+    return engine_lib().h264_amd_build_id().decode()
 
 
 def available():
@@ -123,6 +131,18 @@ class DevBuf:
             pass
 
 
+class ExtBuf:
+    """Device memory owned by somebody else (a torch tensor's storage) seen as
+    a DevBuf: pointer + size, never freed here."""
+
+    def __init__(self, ptr, nbytes):
+        self.ptr = C.c_void_p(int(ptr))
+        self.nbytes = int(nbytes)
+
+    def free(self):
+        pass
+
+
 class Engine:
     """One engine per GPU (struct h264_amd_engine)."""
 
@@ -170,8 +190,20 @@ class Engine:
         _check(engine_lib().h264_amd_memset(self.h, buf.ptr, value,
                                             buf.nbytes), "memset")
 
+    def copy_d2d(self, dst, dst_off, src, src_off, nbytes):
+        _check(engine_lib().h264_amd_copy(
+            self.h, C.c_void_p(dst.ptr.value + dst_off),
+            C.c_void_p(src.ptr.value + src_off), nbytes), "copy")
+
     def sync(self):
         _check(engine_lib().h264_amd_engine_sync(self.h), "sync")
+
+    def probe_read_ms(self, d_buf, length):
+        """one pure streaming read of the buffer (the box's read ceiling)"""
+        ms = C.c_float()
+        _check(engine_lib().h264_amd_probe_read(self.h, d_buf.ptr, length,
+                                                C.byref(ms)), "probe_read")
+        return ms.value
 
     def last_kernel_ms(self, family):
         ms = C.c_float()
@@ -253,15 +285,19 @@ class Engine:
         return out
 
     # -- slice write-back ---------------------------------------------------
-    def write_slices(self, params, d_src, out, out_capacity, sync=True):
+    def write_slices(self, params, d_src, out, out_capacity, sync=True,
+                     fetch=True, d_out=None):
         """Re-serialise the slices of a decode_slices() result `out` (needs
-        want_headers=True).  Returns (d_out, offsets, sizes-as-int32 array)."""
+        want_headers=True).  Returns (d_out, offsets, sizes-as-int32 array);
+        d_out: reuse an output buffer of an earlier call; fetch=False: leave
+        the sizes on the device (timing loops)."""
         n = out["n"]
         cap = (int(out_capacity) + 15) & ~15
         offs = np.arange(n, dtype=np.uint64) * np.uint64(cap)
         d_offs = self.upload(offs)
         d_sizes = self.alloc(4 * n)
-        d_out = self.alloc(n * cap)
+        if d_out is None:
+            d_out = self.alloc(n * cap)
         a = WriteArgs()
         a.d_src = d_src.ptr
         a.d_descs = out["d_descs"].ptr
@@ -277,7 +313,8 @@ class Engine:
                                                   C.byref(a)), "write")
         if sync:
             self.sync()
-        sizes = self.download(d_sizes, 4 * n, dtype=np.int32)
+        sizes = self.download(d_sizes, 4 * n, dtype=np.int32) if fetch else \
+            None
         return d_out, offs, sizes
 
     # -- synthetic slices ---------------------------------------------------

@@ -341,6 +341,18 @@ extern "C" int h264_amd_download(struct h264_amd_engine *e, void *dst,
 	return 0;
 }
 
+extern "C" int h264_amd_copy(struct h264_amd_engine *e, void *d_dst,
+			     const void *d_src, size_t size)
+{
+	if (e == NULL || (size && (d_dst == NULL || d_src == NULL)))
+		return -EINVAL;
+	HIP_TRY(hipSetDevice(e->device));
+	if (size)
+		HIP_TRY(hipMemcpyAsync(d_dst, d_src, size, hipMemcpyDeviceToDevice,
+				       e->stream));
+	return 0;
+}
+
 extern "C" int h264_amd_memset(struct h264_amd_engine *e, void *d_dst, int value,
 			       size_t size)
 {

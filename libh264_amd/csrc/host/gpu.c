@@ -119,3 +119,14 @@ int h264_host_ctx_params(struct h264_ctx *ctx, struct h264_amd_params **ret,
 	*epoch = (uint32_t)res;
 	return 0;
 }
+
+/* Identity of the sources this library was built from (libh264_amd/build.py),
+ * the drop-in library's counterpart of h264_amd_build_id(). */
+#ifndef H264_AMD_BUILD_ID
+#define H264_AMD_BUILD_ID "unidentified"
+#endif
+H264_API const char *h264_amd_dropin_build_id(void)
+{
+	static const char id[] = "h264_amd_build_id=" H264_AMD_BUILD_ID;
+	return id + sizeof("h264_amd_build_id=") - 1;
+}

@@ -519,3 +519,33 @@ static inline void scan_scratch_free(scan_scratch *s)
 }
 
 #endif /* H264_AMD_SCAN_HIP */
+
+/* ---- calibration: what a pure streaming read reaches with the scan's mapping
+ * (one contiguous segment per wave, 16 B per lane, 4 KiB in flight): the
+ * ceiling the scan, write-back and AVCC kernels are held against besides the
+ * nominal HBM peak ("report fractions of both nominal and
+ * measured") ---- */
+extern "C" __global__ void __launch_bounds__(64 * SCAN_WAVES_PER_BLOCK)
+h264_amd_k_probe_read(const uint8_t *buf, uint64_t len, uint32_t seg_bytes,
+		      uint32_t nsegs, uint32_t *sink)
+{
+	const uint32_t seg = blockIdx.x * SCAN_WAVES_PER_BLOCK + (threadIdx.x >> 6);
+	const uint32_t lane = threadIdx.x & 63u;
+	if (seg >= nsegs)
+		return;
+	const uint64_t lo = (uint64_t)seg * seg_bytes;
+	uint64_t hi = lo + seg_bytes;
+	if (hi > len)
+		hi = len;
+	uint32_t acc = 0;
+	for (uint64_t pos = lo; pos + SCAN_BLOCK_BYTES <= hi; pos += SCAN_BLOCK_BYTES) {
+		const uint4 *p = reinterpret_cast<const uint4 *>(buf + pos) + lane;
+		uint4 a = p[0], b = p[64], c = p[128], d = p[192];
+		acc ^= a.x ^ a.y ^ a.z ^ a.w ^ b.x ^ b.y ^ b.z ^ b.w ^ c.x ^ c.y ^
+		       c.z ^ c.w ^ d.x ^ d.y ^ d.z ^ d.w;
+	}
+	/* practically never true, but the compiler cannot know: keeps the loads
+	 * alive (the sink is scratch that every scan clears before use) */
+	if (acc == 0x9e3779b9u)
+		sink[0] = acc;
+}

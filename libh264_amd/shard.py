@@ -19,6 +19,49 @@ def rank_seed(rank, base=17):
     return 1000003 * rank + base
 
 
+def rank_env(env=None, gpus=None):
+    """(rank, world, local_rank) of this process from the launcher's
+    environment (torch.distributed.run sets RANK / WORLD_SIZE / LOCAL_RANK).
+    `gpus`: what the command line asked for; a launcher that started another
+    number of ranks is a mistake worth stopping for."""
+    import os
+    env = os.environ if env is None else env
+    world = int(env.get("WORLD_SIZE", "1"))
+    rank = int(env.get("RANK", "0"))
+    local_rank = int(env.get("LOCAL_RANK", str(rank)))
+    if not (0 <= rank < world):
+        raise RuntimeError("RANK %d outside WORLD_SIZE %d" % (rank, world))
+    if gpus is not None and "WORLD_SIZE" in env and int(gpus) != world:
+        raise RuntimeError("--gpus %d but the launcher started %d ranks" %
+                           (int(gpus), world))
+    return rank, world, local_rank
+
+
+def init_dist(backend, local_rank, env=None):
+    """Join the job's process group.  ORDER MATTERS on the GPU box: torch ships
+    its own ROCm runtime under the same soname as the system one the engine
+    library was linked against; with torch initialised first the engine
+    resolves to that already-loaded copy and the process has ONE HIP runtime
+    (measured both ways, tools/dist_probe.py).  So this runs before the first
+    libh264_amd.Engine() of the process; the engine library loads lazily."""
+    import os
+    import torch.distributed as dist
+    env = os.environ if env is None else env
+    if "MASTER_ADDR" not in env:
+        env["MASTER_ADDR"] = "127.0.0.1"
+        env.setdefault("MASTER_PORT", "29573")
+        env.setdefault("RANK", "0")
+        env.setdefault("WORLD_SIZE", "1")
+    if backend == "nccl":
+        import torch
+        torch.cuda.set_device(local_rank)
+        dist.init_process_group(backend="nccl",
+                                device_id=torch.device("cuda", local_rank))
+    else:
+        dist.init_process_group(backend=backend)
+    return dist
+
+
 def balance(sizes, world):
     """Greedy longest-first partition of slices over `world` ranks by bytes.
     Returns a list of index arrays (ascending inside each rank), covering
