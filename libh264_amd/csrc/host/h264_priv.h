@@ -6,8 +6,10 @@
  * reference's src/h264_priv.h:67-140 and src/h264_reader.c:30-36), parses and
  * serialises the small non-VCL NAL units (parameter sets, SEI, AUD, filler),
  * performs access-unit detection and replays callbacks in bitstream order.
- * Every slice NAL unit -- header and data, reading and writing -- is handed to
- * the MI355X kernels through <h264_amd.h>; there is no CPU slice path here.
+ * Slice NAL units -- header and data, reading and writing -- are handed to
+ * the MI355X kernels through <h264_amd.h>; the one exception is the header of a
+ * single slice whose data nobody asked for (slicehdr.c), and that path too
+ * refuses to run without the engine: there is no CPU fallback here.
  */
 #ifndef H264_AMD_HOST_PRIV_H
 #define H264_AMD_HOST_PRIV_H
@@ -119,6 +121,13 @@ int h264_syn_sei_read(struct h264_bitstream *bs, struct h264_ctx *ctx,
 int h264_syn_sei_write(struct h264_bitstream *bs, struct h264_ctx *ctx);
 int h264_write_one_sei(struct h264_bitstream *bs, struct h264_ctx *ctx,
 		       const struct h264_sei *sei);
+
+/* ---- slicehdr.c: slice header on the host for header-only calls ---- */
+int h264_host_slice_is_header_only(const struct h264_ctx *ctx, uint32_t flags,
+				   const uint8_t *nal, size_t len);
+int h264_host_slice_header(const struct h264_ctx *ctx, const uint8_t *nal,
+			   size_t len, struct h264_amd_slice_result *r,
+			   struct h264_slice_header *sh);
 
 /* ---- engine glue (gpu.c) ---- */
 /* process-wide engine on device $H264_AMD_DEVICE (default 0); -ENODEV when

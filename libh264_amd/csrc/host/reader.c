@@ -454,8 +454,14 @@ static int replay_slice(struct h264_reader *rd, const uint8_t *nal, size_t len,
 
 /* One NAL unit against the context: the READ instantiation of the NAL
  * dispatch (ref src/h264_syntax.h:1446-1604), slices fed from the kernel. */
+struct rd_host_slice {
+	struct h264_amd_slice_result r;
+	struct h264_slice_header sh;
+};
+
 static int replay_nal(struct h264_reader *rd, struct rd_batch *b,
-		      const uint8_t *nal, size_t len, int64_t slice)
+		      const uint8_t *nal, size_t len, int64_t slice,
+		      const struct rd_host_slice *hs)
 {
 	struct h264_ctx *ctx = rd->ctx;
 	const struct h264_ctx_cbs *cbs = &rd->cbs;
@@ -481,6 +487,15 @@ static int replay_nal(struct h264_reader *rd, struct rd_batch *b,
 		struct h264_amd_slice_result big;
 		const uint32_t *t0;
 		size_t k;
+		if (hs != NULL) {
+			/* header parsed on the host (slicehdr.c) */
+			res = replay_slice(rd, nal, len, &hs->r, &hs->sh, NULL);
+			if (res < 0)
+				return res;
+			if (cbs->slice)
+				cbs->slice(ctx, nal, len, &ctx->slice.hdr, ud);
+			break;
+		}
 		if (slice < 0 || b == NULL)
 			return -EPROTO;
 		res = batch_fetch(rd, b, (size_t)slice);
@@ -606,7 +621,7 @@ static int run(struct h264_reader *rd, uint32_t flags, const uint8_t *buf,
 	for (i = 0; i < n && !(stream && rd->stop); i++) {
 		last = replay_nal(rd, b, buf + nals[i].start,
 				  (size_t)(nals[i].end - nals[i].start),
-				  plan[i].slice);
+				  plan[i].slice, NULL);
 		if (last == -ENODEV || last == -ENOMEM) {
 			*fatal = last;
 			break;
@@ -698,7 +713,21 @@ int h264_reader_parse_nalu(struct h264_reader *rd, uint32_t flags,
 	}
 	res = h264_host_engine(&eng);
 	if (res < 0)
+		return res; /* no engine, no slice path: not even this one */
+	if (h264_host_slice_is_header_only(rd->ctx, flags, buf, len) &&
+	    getenv("H264_AMD_NO_HOST_HEADERS") == NULL) {
+		/* one slice whose data nobody looks at: a few dozen bytes of
+		 * header are read here instead of crossing PCIe twice around a
+		 * kernel launch (slicehdr.c) */
+		struct rd_host_slice *hs = malloc(sizeof(*hs));
+		if (hs == NULL)
+			return -ENOMEM;
+		res = h264_host_slice_header(rd->ctx, buf, len, &hs->r, &hs->sh);
+		if (res == 0)
+			res = replay_nal(rd, NULL, buf, len, -1, hs);
+		free(hs);
 		return res;
+	}
 	h264_host_lock();
 	res = h264_host_grow(&rd->d_buf, &rd->d_buf_cap, len + 64);
 	if (res == 0)

@@ -735,7 +735,7 @@ __device__ __forceinline__ uint32_t sd_level_escape(WaveBits &wb, uint32_t lane,
 /* 9.2 residual_block (ref src/h264_syntax_slice_data.h:103-242).  The decoded
  * levels go to stage[coef_off ...] (int16 units from the record start).
  * Returns TotalCoeff.  Malformed codes do not branch out: they raise a flag
- * (serr: scalar, verr: any lane) and the walk goes on with benign values until
+ * (serr) and the walk goes on with benign values until
  * the caller looks at them.
  *
  * Division of labour (profiles/r02_decode_cost_model.md): the bit cursor and
@@ -749,7 +749,7 @@ __device__ __forceinline__ uint32_t sd_level_escape(WaveBits &wb, uint32_t lane,
 __device__ __forceinline__ uint32_t
 sd_residual_block(VBits &vb, WaveBits &wb, const VlcTabs &vt, uint32_t lane,
 		  uint8_t *stage, uint32_t cls, uint32_t bits, uint32_t maxnum,
-		  uint32_t coef_off, uint32_t &serr, uint32_t &verr)
+		  uint32_t coef_off, uint32_t &serr)
 {
 	/* ---- coeff_token; bits: the peek at the cursor, which the block loop
 	 * already has ---- */
@@ -922,13 +922,15 @@ sd_residual_block(VBits &vb, WaveBits &wb, const VlcTabs &vt, uint32_t lane,
 	uint32_t ng = codes & 1u;
 	uint32_t lv = ((((codes + 2u) >> 1) ^ (0u - ng)) + ng) & 0xffffu;
 	uint32_t pos = zl + tc - 1u - lane;
-	bool mine = lane < tc;
-	/* malformed: outside the block (Appendix C.5) */
-	bool outside = mine && pos >= maxnum;
-	verr |= outside ? 1u : 0u;
+	/* A position outside the block (damaged stream: index 15 of a
+	 * 15-coefficient block) is dropped and the walk goes on, which is what
+	 * the reference's unchecked store amounts to for everything it makes
+	 * observable (ref src/h264_syntax_slice_data.h:222-226; the argument is
+	 * in oracle/orc_cavlc.c at the same place). */
+	bool mine = lane < tc && pos < maxnum;
 	*reinterpret_cast<uint16_t *>(
 		lds_sel(stage + H264_AMD_T2_HEAD + 2u * (coef_off + pos),
-			stage - SD_DUMP_BYTES, mine && !outside, lane)) = (uint16_t)lv;
+			stage - SD_DUMP_BYTES, mine, lane)) = (uint16_t)lv;
 	return tc;
 }
 
@@ -1416,7 +1418,7 @@ sd_slice_data(WaveBits &wb, const VlcTabs &vt, uint32_t cbp_map, uint32_t lane,
 					todo |= c << 17;
 				}
 				const uint32_t vinfo = i16 ? m.info_i16 : m.info_n;
-				uint32_t serr = 0, verr = 0;
+				uint32_t serr = 0;
 				while (todo) {
 					vb_sync(vb, wb, lane);
 					vb_norm(vb, wb);
@@ -1472,12 +1474,12 @@ sd_slice_data(WaveBits &wb, const VlcTabs &vt, uint32_t cbp_map, uint32_t lane,
 					uint32_t tc = sd_residual_block(
 						vb, wb, vt, lane, stage, cls, peek,
 						(info >> 6) & 31u,
-						(info >> 13) & 0x7ffu, serr, verr);
+						(info >> 13) & 0x7ffu, serr);
 					/* TotalCoeff is recorded for every class, DC
 					 * blocks included (Appendix C.4) */
 					sd_nz_set(m, nzlane, tc, lane);
 				}
-				if (serr || vb_true(verr != 0))
+				if (serr)
 					return -EIO;
 			}
 		}

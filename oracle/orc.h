@@ -238,6 +238,7 @@ struct orc_reader {
 
 /* ---- bit level (orc_bits.c; ref include/h264/h264_bitstream.h,
  *      src/h264_bitstream.c) -------------------------------------------- */
+extern uint64_t orc_stat_dropped_coeffs; /* test instrumentation */
 int orc_find_nalu(const uint8_t *buf, size_t len, size_t *start, size_t *end);
 int orc_bs_fetch(struct h264_bitstream *bs);
 int orc_bs_read_bits(struct h264_bitstream *bs, uint32_t *v, uint32_t n);

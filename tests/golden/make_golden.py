@@ -55,6 +55,41 @@ def damaged(name, cfg, seed0):
     return len(blob)
 
 
+def overflow(name, cfg, seed0, want_cases=8):
+    """Damaged slices in which a coefficient lands OUTSIDE its block (index 15
+    of an Intra16x16 AC / chroma AC block): the reference stores unchecked and
+    goes on (src/h264_syntax_slice_data.h:222-226), so must oracle and kernel
+    -- an earlier restatement stopped there with -EIO and delivered fewer
+    macroblocks than the reference.  Found by a seeded search over bit flips of
+    generated slices; kept: cases where the walk goes on for at least one more
+    macroblock."""
+    dropped = C.c_uint64.in_dll(orc.lib(), "orc_stat_dropped_coeffs")
+    head = [gen.sps(cfg), gen.pps(cfg)]
+    rnd = random.Random(seed0)
+    keep = []
+    tries = 0
+    while len(keep) < want_cases and tries < 20000:
+        tries += 1
+        st = (2, 0, 1)[tries % 3]
+        nal = bytearray(gen.slice_nal(cfg, streams.rich_slice(
+            cfg, 1000 + tries % 97, st, pm_i16x16=600, density=9)))
+        for _ in range(rnd.randrange(1, 4)):
+            p = rnd.randrange(4, len(nal))
+            nal[p] ^= 1 << rnd.randrange(8)
+        before = dropped.value
+        rec = orc.parse_nalus(head + [bytes(nal)], want=0)
+        if dropped.value > before and rec.results[0].mb_count >= 4:
+            keep.append(bytes(nal))
+    assert len(keep) == want_cases, (len(keep), tries)
+    nals = head + keep
+    rec = orc.parse_nalus(nals, want=orc.ORC_REC_WANT_T2)
+    blob = b"".join(nals)
+    sizes = np.array([len(n) for n in nals], dtype=np.uint32)
+    golden_io.save(os.path.join(HERE, name), blob, rec, nal_sizes=sizes,
+                   statuses=np.array(rec.statuses, dtype=np.int32))
+    return len(blob), tries
+
+
 def ps_1080p(entropy):
     sps = Sps()
     sps.profile_idc = 100
@@ -141,6 +176,8 @@ def main():
                           bottom_field_pic_order_in_frame_present_flag=1),
         60, 10, types=(2, 0, 1, 3, 4)))
     print("damaged_small", damaged("damaged_small", streams.small_cfg(), 9))
+    print("damaged_overflow", overflow("damaged_overflow", streams.small_cfg(),
+                                       77))
     synth("synth_grid")
     cabac("cabac_init")
     for f in sorted(os.listdir(HERE)):

@@ -91,8 +91,9 @@ def test_dropin_reader_vs_golden(name):
     assert bytes(got.headers) == ex["headers"].tobytes()
 
 
-def test_dropin_reader_damaged_vs_golden():
-    fx = golden_io.load(os.path.join(GOLDEN, "damaged_small"))
+@pytest.mark.parametrize("name", ["damaged_small", "damaged_overflow"])
+def test_dropin_reader_damaged_vs_golden(name):
+    fx = golden_io.load(os.path.join(GOLDEN, name))
     sizes = fx["extra"]["nal_sizes"]
     offs = np.concatenate([[0], np.cumsum(sizes)]).astype(int)
     nals = [fx["stream"][offs[i]:offs[i + 1]] for i in range(len(sizes))]
@@ -101,6 +102,37 @@ def test_dropin_reader_damaged_vs_golden():
     have = np.array(got.event_tuples(), dtype=np.uint64).reshape(-1, 4)
     assert np.array_equal(have, fx["expect"]["events"])
     assert bytes(got.headers) == fx["expect"]["headers"].tobytes()
+
+
+def test_decode_kernel_out_of_block_coefficients_vs_golden(engine):
+    """damaged_overflow: slices that put a coefficient at index 15 of a
+    15-coefficient block.  The kernel drops it and walks on like the reference
+    (full T2 records and results as recorded)."""
+    fx = golden_io.load(os.path.join(GOLDEN, "damaged_overflow"))
+    ex = fx["expect"]
+    sizes = fx["extra"]["nal_sizes"]
+    offs = np.concatenate([[0], np.cumsum(sizes)]).astype(int)
+    data = fx["stream"]
+    params = Params()
+    params.put_sps(structs(ex["sps"], Sps)[0])
+    epoch = params.put_pps(structs(ex["pps"], Pps)[0])
+    d_buf = engine.upload(np.frombuffer(data + b"\xff" * 64, dtype=np.uint8))
+    descs = [(int(offs[i]), int(sizes[i]), epoch)
+             for i in range(2, len(sizes))]
+    want = structs(ex["results"], SliceResult)
+    assert len(want) == len(descs) == 8
+    out = engine.decode_slices(params, d_buf, descs, reader_flags=1,
+                               tier=TIER_T2,
+                               mb_capacity=max(w.mb_count for w in want) + 2,
+                               want_headers=True)
+    res = engine.fetch_results(out)
+    for i, w in enumerate(want):
+        assert bytes(res[i]) == bytes(w), i
+        st = t2_stride(w.chroma_array_type)
+        off = int(ex["mboffs"][i])
+        exp = ex["mbrecs"][off:off + w.mb_count * st].reshape(w.mb_count, st)
+        assert np.array_equal(engine.fetch_mb(out, i, w.mb_count)[:, :st],
+                              exp), i
 
 
 def test_synth_and_cabac_kernels_vs_golden(engine):

@@ -264,10 +264,19 @@ def split_nals(fx):
     return [fx["stream"][offs[i]:offs[i + 1]] for i in range(len(sizes))]
 
 
-def test_oracle_reproduces_golden_damaged():
+@pytest.mark.parametrize("name", ["damaged_small", "damaged_overflow"])
+def test_oracle_reproduces_golden_damaged(name):
     import golden_io
-    fx = golden_io.load(os.path.join(GOLDEN, "damaged_small"))
+    fx = golden_io.load(os.path.join(GOLDEN, name))
+    dropped = C.c_uint64.in_dll(orc.lib(), "orc_stat_dropped_coeffs")
+    before = dropped.value
     rec = orc.parse_nalus(split_nals(fx), want=orc.ORC_REC_WANT_T2)
+    if name == "damaged_overflow":
+        # every slice of this fixture places a coefficient outside its block
+        # and the walk goes on, as the reference's does
+        # (src/h264_syntax_slice_data.h:222-226)
+        assert dropped.value - before >= len(rec.results) == 8
+        assert all(r.mb_count >= 4 for r in rec.results)
     assert rec.statuses == list(fx["extra"]["statuses"])
     got = golden_io.summarise(rec)
     for key in ("events", "headers", "results", "mbrecs"):
