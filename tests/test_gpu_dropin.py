@@ -435,3 +435,34 @@ def test_ctx_clear_then_other_parameter_sets():
     assert 8 * bs2.off + bs2.cachebits == r.hdr_len_bits
     assert buf2.raw[:bs2.off] == nal[:bs2.off]
     ctx.close()
+
+
+@pytest.mark.parametrize("cabac", [0, 1])
+def test_single_nal_header_on_the_host_equals_device_path(monkeypatch, cabac):
+    """h264_reader_parse_nalu(flags = 0) reads a slice header on the host
+    (csrc/host/slicehdr.c); with H264_AMD_NO_HOST_HEADERS the same call goes
+    through the kernel.  Both must deliver the oracle's event log, statuses and
+    header images -- clean and damaged NAL units, header extras (reordering,
+    weights, marking), field pictures, and CABAC pictures with SLICE_DATA set
+    (no slice data walk there, src/h264_syntax_slice_data.h:715-717)."""
+    kw = dict(weighted_pred_flag=1, weighted_bipred_idc=1, field_coding=1,
+              pic_order_cnt_type=1,
+              bottom_field_pic_order_in_frame_present_flag=1)
+    if cabac:
+        kw.update(entropy_coding_mode_flag=1, profile_idc=100)
+    cfg = streams.small_cfg(**kw)
+    nals = mixed_nals(cfg, n_slices=30, seed0=200)
+    if not cabac:
+        nals = streams.damage(nals, 11)
+    nals.insert(7, b"\x65")
+    nals.insert(9, b"\x41\x9a")
+    flags = 1 if cabac else 0
+    ref = orc.parse_nalus(nals, flags=flags, want=0)
+    host = prod.parse_nalus(nals, flags=flags)
+    monkeypatch.setenv("H264_AMD_NO_HOST_HEADERS", "1")
+    dev = prod.parse_nalus(nals, flags=flags)
+    for got in (host, dev):
+        assert got.statuses == ref.statuses
+        same_log(ref, got, stream=False)
+    assert any(s < 0 for s in ref.statuses) or cabac
+    assert sum(1 for e in ref.event_tuples() if e[0] == 4) >= 20
