@@ -1,8 +1,7 @@
 /**
  * libh264_amd -- MI355X-native H.264 bitstream parse/serialise engine behind
  * the libh264 C API.  Umbrella header, drop-in for the reference's
- * include/h264/h264.h (include order ref :50-58).  The JSON dump API
- * (h264_dump.h, needs json-c) is not part of this build: see DESIGN.md.
+ * include/h264/h264.h (include order ref :50-58).
  */
 #ifndef _H264_H_
 #define _H264_H_
@@ -26,6 +25,7 @@ extern "C" {
 #include "h264/h264_types.h"
 #include "h264/h264_bitstream.h"
 #include "h264/h264_ctx.h"
+#include "h264/h264_dump.h"
 #include "h264/h264_reader.h"
 #include "h264/h264_writer.h"
 

@@ -4,9 +4,13 @@
  * oracle/evlog.h, so that tests can compare it byte for byte with the log the
  * oracle's recorder (oracle/orc_api.c) produces for the same input.
  * With want & 2 every parsed NAL unit is written back from nalu_end with
- * h264_write_nalu(), like the reference's dump tool does (tools/h264_dump.c).
+ * h264_write_nalu(), like the reference's dump tool does (tools/h264_dump.c);
+ * with want & 4 every NAL unit is also dumped from nalu_end with
+ * h264_dump_nalu(H264_DUMP_FLAGS_SLICE_DATA), one JSON text per line, again
+ * like that tool (tools/h264_dump.c:195-227).
  */
 #include <errno.h>
+#include <stdio.h>
 #include <stdlib.h>
 #include <string.h>
 
@@ -15,6 +19,7 @@
 #include "../../oracle/evlog.h"
 
 #define REC_WANT_REWRITE 0x2
+#define REC_WANT_DUMP 0x4
 
 struct rec_rewrite {
 	uint64_t off;
@@ -29,7 +34,8 @@ struct rec {
 	const uint8_t *base;
 	uint32_t flags, want;
 	uint32_t nal_index;
-	struct evvec events, sps, pps, headers, rewrites, rewrite_idx;
+	struct evvec events, sps, pps, headers, rewrites, rewrite_idx, dumps;
+	struct h264_dump *dump;
 };
 
 static void cb_au_end(struct h264_ctx *ctx, void *ud)
@@ -56,6 +62,26 @@ static void cb_nalu_end(struct h264_ctx *ctx, enum h264_nalu_type type,
 	struct rec *r = ud;
 	ev_push(&r->events, EV_NALU_END, type | (nh->nal_ref_idc << 8),
 		(uint64_t)(buf - r->base), len);
+	if (r->want & REC_WANT_DUMP) {
+		const char *str = NULL;
+		char num[32];
+		int res;
+		if (r->dump == NULL) {
+			struct h264_dump_cfg cfg = {H264_DUMP_TYPE_JSON};
+			if (h264_dump_new(&cfg, &r->dump) < 0)
+				abort();
+		}
+		res = h264_dump_nalu(r->dump, ctx, H264_DUMP_FLAGS_SLICE_DATA);
+		if (res >= 0)
+			res = h264_dump_get_json_str(r->dump, &str);
+		if (res >= 0) {
+			evvec_push(&r->dumps, str, strlen(str));
+		} else {
+			int n = snprintf(num, sizeof(num), "ERR %d", res);
+			evvec_push(&r->dumps, num, (size_t)n);
+		}
+		evvec_push(&r->dumps, "\n", 1);
+	}
 	if ((r->want & REC_WANT_REWRITE) && !h264_ctx_is_nalu_unknown(ctx)) {
 		struct h264_bitstream bs;
 		struct rec_rewrite w;
@@ -225,6 +251,8 @@ void rec_free(struct rec *r)
 	evvec_free(&r->headers);
 	evvec_free(&r->rewrites);
 	evvec_free(&r->rewrite_idx);
+	evvec_free(&r->dumps);
+	h264_dump_destroy(r->dump);
 	free(r);
 }
 
@@ -272,3 +300,4 @@ ACCESSOR(pps, pps, struct h264_pps)
 ACCESSOR(headers, headers, struct h264_slice_header)
 ACCESSOR(rewrites, rewrites, uint8_t)
 ACCESSOR(rewrite_idx, rewrite_idx, struct rec_rewrite)
+ACCESSOR(dumps, dumps, uint8_t)

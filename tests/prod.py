@@ -14,6 +14,7 @@ _REC = None
 _H264 = None
 
 WANT_REWRITE = 2
+WANT_DUMP = 4
 READER_FLAGS_SLICE_DATA = 1
 
 
@@ -85,7 +86,7 @@ def recorder():
         L.rec_ctx.restype = C.c_void_p
         L.rec_ctx.argtypes = [C.c_void_p]
         for name in ("events", "sps", "pps", "headers", "rewrites",
-                     "rewrite_idx"):
+                     "rewrite_idx", "dumps"):
             f = getattr(L, "rec_" + name)
             f.restype = C.c_void_p
             f.argtypes = [C.c_void_p, C.POINTER(C.c_size_t)]
@@ -115,6 +116,7 @@ class Recording:
         self.headers = grab("headers", SliceHeader)
         self.rewrites = bytes(grab("rewrites", C.c_uint8))
         self.rewrite_idx = grab("rewrite_idx", Rewrite)
+        self.dumps = bytes(grab("dumps", C.c_uint8)).decode()
         self.consumed = None
         self.result = None
         self._keep = keep

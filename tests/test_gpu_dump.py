@@ -1,0 +1,173 @@
+"""JSON dump (include/h264/h264_dump.h, libh264_amd/csrc/host/dump.c): every
+NAL unit of a mixed stream is dumped from nalu_end with
+h264_dump_nalu(H264_DUMP_FLAGS_SLICE_DATA), the way the reference's tool does
+(tools/h264_dump.c:195-227), and the JSON is walked the way the reference's
+tests/check_stream.py walks it (:176-249) -- against the oracle's structs and
+full macroblock records.  The reference's own text is not available here
+(json-c is not in the image): what is pinned is the content and the key names
+the reference derives from its struct members (src/h264_dump.c:154-191)."""
+import ctypes as C
+import json
+
+import numpy as np
+import pytest
+
+import orc
+import prod
+import streams
+from libh264_amd import gen
+from libh264_amd.ctypes_abi import SliceHeader, Sps, Pps, t2_stride
+
+pytestmark = pytest.mark.gpu
+
+
+def coefs_of(rec, cat, i16):
+    """{key: level} as the reference names coefficients (name(blk,idx))"""
+    co = rec[256:].view(np.int16)
+    out = {}
+
+    def block(name, blk, base, n):
+        for i in range(n):
+            if co[base + i]:
+                out["%s(%d,%d)" % (name, blk, i)] = int(co[base + i])
+    ncomp = 3 if cat == 3 else 1
+    cbp = int(rec[1])
+    for c in range(ncomp):
+        base = 256 * c
+        if i16:
+            block(("Luma16DC", "Cb16DC", "Cr16DC")[c], 0, base, 16)
+        for b in range(16):
+            if not cbp & (1 << (b >> 2)):
+                continue
+            if i16:
+                block(("Luma16AC", "Cb16AC", "Cr16AC")[c], b,
+                      base + 16 + 15 * b, 15)
+            else:
+                block(("Luma", "Cb", "Cr")[c], b, base + 16 * b, 16)
+    if cat in (1, 2):
+        n = 4 if cat == 1 else 8
+        if (cbp >> 4) & 3:
+            block("CbDC", 0, 256, n)
+            block("CrDC", 0, 256 + n, n)
+        if (cbp >> 4) & 2:
+            for c in range(2):
+                for b in range(n):
+                    block(("CbAC", "CrAC")[c], b,
+                          256 + 2 * n + 15 * (n * c + b), 15)
+    return out
+
+
+@pytest.mark.parametrize("cf", [1, 3])
+def test_dump_walk(cf):
+    cfg = streams.small_cfg(cf=cf, weighted_pred_flag=1)
+    nals = streams.mixed_nals(cfg, n_slices=10, seed0=300)
+    data = streams.annexb(nals)
+    ref = orc.parse_stream(data, want=orc.ORC_REC_WANT_T2)
+    got = prod.parse_stream(data, want=prod.WANT_DUMP)
+    lines = got.dumps.strip().split("\n")
+    ends = [e for e in ref.event_tuples() if e[0] == 3]
+    assert len(lines) == len(ends)
+    n_slice = n_sps = n_pps = 0
+    for line, ev in zip(lines, ends):
+        assert not line.startswith("ERR"), line
+        j = json.loads(line)
+        hdr = j["nalu_header"]
+        assert hdr["forbidden_zero_bit"] == 0
+        assert hdr["nal_unit_type"] == ev[1] & 0xff
+        assert hdr["nal_ref_idc"] == ev[1] >> 8
+        t = hdr["nal_unit_type"]
+        if t == 7:
+            sps = ref.sps[n_sps]
+            n_sps += 1
+            for k, v in j["sps"].items():
+                if isinstance(v, int):
+                    assert v == getattr(sps, k), k
+            assert j["sps"]["pic_width_in_mbs_minus1"] == cfg.width_mbs - 1
+        elif t == 8:
+            pps = ref.pps[n_pps]
+            n_pps += 1
+            for k, v in j["pps"].items():
+                if isinstance(v, int):
+                    assert v == getattr(pps, k), k
+        elif t in (1, 5):
+            sh = ref.headers[n_slice]
+            r = ref.results[n_slice]
+            js = j["slice"]
+            for k, v in js["slice_header"].items():
+                if isinstance(v, int):
+                    assert v == getattr(sh, k), k
+            assert "rplm" in js["slice_header"]
+            mbs = js["slice_data"]["mb"]
+            recs = ref.mb_records(n_slice)
+            st = t2_stride(r.chroma_array_type)
+            m = 0
+            for item in mbs:
+                if "mb_skip_run" in item:
+                    for _ in range(item["mb_skip_run"]):
+                        assert recs[m][2] & 1  # skipped
+                        m += 1
+                    continue
+                rec = recs[m][:st]
+                assert not rec[2] & 1
+                assert item["mbAddr"] == r.first_mb_in_slice + m
+                assert item["mb_addr"] == sh.frame_num * 10000 + item["mbAddr"]
+                assert item["mb_type"] == rec[3]
+                assert item["MbaffFrameFlag"] == 0
+                mb_type = int(rec[0])  # enum h264_mb_type
+                I_NXN, I_16X16, I_PCM = 1, 2, 3
+                if mb_type == I_PCM:
+                    assert item["pcm_sample_luma"] == \
+                        rec[256:768].view(np.uint16).tolist()
+                else:
+                    if mb_type != I_16X16:
+                        assert item["coded_block_pattern"] == rec[1]
+                    want = coefs_of(rec, r.chroma_array_type,
+                                    mb_type == I_16X16)
+                    have = item.get("residual", {})
+                    assert have == want, (n_slice, m)
+                    if "residual" in item:
+                        assert item["mb_qp_delta"] == \
+                            int(rec[4:6].view(np.int16)[0])
+                    if mb_type == I_NXN and not rec[2] & 2:  # 4x4 modes
+                        modes = [((int(rec[8 + i // 2]) >> (4 * (i & 1))) & 15)
+                                 - 1 for i in range(16)]
+                        assert item["intra4x4_pred_mode"] == modes
+                m += 1
+            assert m == r.mb_count
+            n_slice += 1
+    assert n_slice == len(ref.results) >= 10 and n_sps >= 1 and n_pps >= 1
+
+
+def test_dump_text_form_and_object_semantics():
+    """json-c's default text form (spaced), get_json_object answers -ENOSYS,
+    and clear / destroy behave."""
+    H = prod.h264()
+    H.h264_dump_new.argtypes = [C.c_void_p, C.POINTER(C.c_void_p)]
+    H.h264_dump_destroy.argtypes = [C.c_void_p]
+    H.h264_dump_clear.argtypes = [C.c_void_p]
+    H.h264_dump_get_json_str.argtypes = [C.c_void_p, C.POINTER(C.c_char_p)]
+    H.h264_dump_get_json_object.argtypes = [C.c_void_p,
+                                            C.POINTER(C.c_void_p)]
+    H.h264_dump_nalu.argtypes = [C.c_void_p, C.c_void_p, C.c_uint32]
+    cfg = (C.c_int * 1)(0)
+    d = C.c_void_p()
+    assert H.h264_dump_new(None, C.byref(d)) == -22
+    assert H.h264_dump_new(cfg, C.byref(d)) == 0
+    s = C.c_char_p()
+    assert H.h264_dump_get_json_str(d, C.byref(s)) == 0 and s.value == b"{ }"
+    o = C.c_void_p()
+    assert H.h264_dump_get_json_object(d, C.byref(o)) == -38  # -ENOSYS
+    ctx = C.c_void_p()
+    assert H.h264_ctx_new(C.byref(ctx)) == 0
+    from libh264_amd.ctypes_abi import NaluHeader
+    nh = NaluHeader(0, 0, 9)
+    assert H.h264_ctx_set_nalu_header(ctx, C.byref(nh)) == 0
+    assert H.h264_dump_nalu(d, ctx, 0) == 0
+    assert H.h264_dump_get_json_str(d, C.byref(s)) == 0
+    assert s.value == (b'{ "nalu_header": { "forbidden_zero_bit": 0, '
+                       b'"nal_ref_idc": 0, "nal_unit_type": 9 }, '
+                       b'"aud": { "primary_pic_type": 0 } }')
+    assert H.h264_dump_clear(d) == 0
+    assert H.h264_dump_get_json_str(d, C.byref(s)) == 0 and s.value == b"{ }"
+    assert H.h264_dump_destroy(d) == 0 and H.h264_dump_destroy(None) == 0
+    H.h264_ctx_destroy(ctx)
