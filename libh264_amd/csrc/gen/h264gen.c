@@ -305,7 +305,42 @@ int h264gen_pps(const struct h264gen_cfg *c, uint8_t *out, size_t cap)
 	bw_ue(&w, c->sps_id);
 	bw_u(&w, c->entropy_coding_mode_flag, 1);
 	bw_u(&w, c->bottom_field_pic_order_in_frame_present_flag, 1);
-	bw_ue(&w, 0); /* num_slice_groups_minus1 */
+	bw_ue(&w, c->num_slice_groups_minus1);
+	if (c->num_slice_groups_minus1 > 0) {
+		uint32_t i, units = c->width_mbs * c->height_mbs;
+		bw_ue(&w, c->slice_group_map_type);
+		switch (c->slice_group_map_type) {
+		case 0:
+			for (i = 0; i <= c->num_slice_groups_minus1; i++)
+				bw_ue(&w, c->run_length_minus1[i]);
+			break;
+		case 2:
+			for (i = 0; i < c->num_slice_groups_minus1; i++) {
+				bw_ue(&w, c->top_left[i]);
+				bw_ue(&w, c->bottom_right[i]);
+			}
+			break;
+		case 3:
+		case 4:
+		case 5:
+			bw_u(&w, c->slice_group_change_direction_flag, 1);
+			bw_ue(&w, c->slice_group_change_rate_minus1);
+			break;
+		case 6: {
+			/* Ceil(Log2(num_slice_groups_minus1 + 1)) bits per id */
+			uint32_t bits = 0;
+			while ((1u << bits) < c->num_slice_groups_minus1 + 1u)
+				bits++;
+			bw_ue(&w, units - 1u); /* pic_size_in_map_units_minus1 */
+			for (i = 0; i < units; i++)
+				if (bits)
+					bw_u(&w, c->slice_group_id[i & 255u], (int)bits);
+			break;
+		}
+		default:
+			break;
+		}
+	}
 	bw_ue(&w, c->num_ref_idx_l0_default_minus1);
 	bw_ue(&w, c->num_ref_idx_l1_default_minus1);
 	bw_u(&w, c->weighted_pred_flag, 1);
@@ -377,7 +412,154 @@ struct gen {
 	uint8_t *nz; /* [num_mbs][48] */
 	uint8_t *t2;
 	uint32_t t2_stride;
+	/* slice groups: address of macroblock i, and which i an address has
+	 * (-1: not part of this slice); NULL without slice groups */
+	uint32_t *addr_of;
+	int32_t *idx_of;
+	uint32_t n_addr;
 };
+
+/* ---- slice groups (8.2.2), written from the standard ------------------------- */
+
+static uint32_t fmo_units0(const struct h264gen_cfg *c, uint32_t cycle)
+{
+	/* MapUnitsInSliceGroup0 = Min(slice_group_change_cycle *
+	 * SliceGroupChangeRate, PicSizeInMapUnits) (7-34) */
+	uint64_t v = (uint64_t)cycle * (c->slice_group_change_rate_minus1 + 1u);
+	uint32_t units = c->width_mbs * c->height_mbs;
+	return v < units ? (uint32_t)v : units;
+}
+
+static void fmo_map_units(const struct h264gen_cfg *c, uint32_t cycle,
+			  uint8_t *m)
+{
+	const uint32_t W = c->width_mbs, H = c->height_mbs, n = W * H;
+	const uint32_t G = c->num_slice_groups_minus1 + 1u;
+	const uint32_t dir = c->slice_group_change_direction_flag ? 1u : 0u;
+	const uint32_t u0 = fmo_units0(c, cycle);
+	const uint32_t upper = dir ? n - u0 : u0; /* sizeOfUpperLeftGroup */
+	uint32_t i, j, k, g;
+	switch (c->slice_group_map_type) {
+	case 0: /* 8.2.2.1 interleaved */
+		i = 0;
+		do {
+			for (g = 0; g < G && i < n;
+			     i += c->run_length_minus1[g++] + 1u)
+				for (j = 0; j <= c->run_length_minus1[g] &&
+					    i + j < n;
+				     j++)
+					m[i + j] = (uint8_t)g;
+		} while (i < n);
+		break;
+	case 1: /* 8.2.2.2 dispersed */
+		for (i = 0; i < n; i++)
+			m[i] = (uint8_t)(((i % W) + (((i / W) * G) / 2u)) % G);
+		break;
+	case 2: /* 8.2.2.3 foreground with left-over */
+		for (i = 0; i < n; i++)
+			m[i] = (uint8_t)(G - 1u);
+		for (g = G - 1u; g-- > 0;) {
+			uint32_t yt = c->top_left[g] / W, xl = c->top_left[g] % W;
+			uint32_t yb = c->bottom_right[g] / W;
+			uint32_t xr = c->bottom_right[g] % W, x, y;
+			for (y = yt; y <= yb && y < H; y++)
+				for (x = xl; x <= xr; x++)
+					m[y * W + x] = (uint8_t)g;
+		}
+		break;
+	case 3: { /* 8.2.2.4 box-out */
+		int32_t x = (int32_t)((W - dir) / 2u), y = (int32_t)((H - dir) / 2u);
+		int32_t left = x, right = x, top = y, bottom = y;
+		int32_t xd = (int32_t)dir - 1, yd = (int32_t)dir;
+		uint32_t vacant;
+		for (i = 0; i < n; i++)
+			m[i] = 1;
+		for (k = 0; k < u0; k += vacant) {
+			vacant = m[(uint32_t)y * W + (uint32_t)x] == 1;
+			if (vacant)
+				m[(uint32_t)y * W + (uint32_t)x] = 0;
+			if (xd == -1 && x == left) {
+				left = left - 1 > 0 ? left - 1 : 0;
+				x = left;
+				xd = 0;
+				yd = 2 * (int32_t)dir - 1;
+			} else if (xd == 1 && x == right) {
+				right = right + 1 < (int32_t)W - 1 ? right + 1
+								   : (int32_t)W - 1;
+				x = right;
+				xd = 0;
+				yd = 1 - 2 * (int32_t)dir;
+			} else if (yd == -1 && y == top) {
+				top = top - 1 > 0 ? top - 1 : 0;
+				y = top;
+				xd = 1 - 2 * (int32_t)dir;
+				yd = 0;
+			} else if (yd == 1 && y == bottom) {
+				bottom = bottom + 1 < (int32_t)H - 1 ? bottom + 1
+								     : (int32_t)H - 1;
+				y = bottom;
+				xd = 2 * (int32_t)dir - 1;
+				yd = 0;
+			} else {
+				x += xd;
+				y += yd;
+			}
+		}
+		break;
+	}
+	case 4: /* 8.2.2.5 raster scan */
+		for (i = 0; i < n; i++)
+			m[i] = (uint8_t)(i < upper ? dir : 1u - dir);
+		break;
+	case 5: /* 8.2.2.6 wipe */
+		k = 0;
+		for (j = 0; j < W; j++)
+			for (i = 0; i < H; i++)
+				m[i * W + j] = (uint8_t)(k++ < upper ? dir : 1u - dir);
+		break;
+	case 6: /* 8.2.2.7 explicit */
+		for (i = 0; i < n; i++)
+			m[i] = c->slice_group_id[i & 255u];
+		break;
+	default:
+		memset(m, 0, n);
+		break;
+	}
+}
+
+long h264gen_mb_to_slice_group_map(const struct h264gen_cfg *c, uint32_t cycle,
+				   uint32_t field_pic, uint8_t *map, size_t cap)
+{
+	const uint32_t W = c->width_mbs, units = W * c->height_mbs;
+	/* macroblocks of the picture: a frame of interlaced material has two
+	 * map-unit rows' worth per unit row (7-27 ff.) */
+	const uint32_t n = (c->field_coding && !field_pic) ? 2u * units : units;
+	uint8_t *m;
+	uint32_t a;
+	if (W == 0 || units == 0 || units > (1u << 22) || n > cap)
+		return -EINVAL;
+	if (c->num_slice_groups_minus1 == 0) {
+		memset(map, 0, n);
+		return (long)n;
+	}
+	m = malloc(units);
+	if (m == NULL)
+		return -ENOMEM;
+	fmo_map_units(c, cycle, m);
+	/* 8.2.2.8: map units are macroblocks for frame_mbs_only and for field
+	 * pictures, macroblock pairs with MBAFF, and otherwise (frame picture
+	 * of interlaced material) a unit covers two vertically adjacent rows */
+	for (a = 0; a < n; a++) {
+		if (!c->field_coding || field_pic)
+			map[a] = m[a];
+		else if (c->field_coding == 2)
+			map[a] = m[a / 2u];
+		else
+			map[a] = m[(a / (2u * W)) * W + (a % W)];
+	}
+	free(m);
+	return (long)n;
+}
 
 static uint8_t *rec_of(struct gen *g, uint32_t i)
 {
@@ -393,10 +575,17 @@ static int16_t *coef_of(uint8_t *rec)
 static uint32_t neighbour_nc(struct gen *g, uint32_t i, uint32_t comp,
 			     uint32_t blk, int chroma)
 {
-	uint32_t addr = g->s->first_mb + i;
+	uint32_t addr = g->addr_of ? g->addr_of[i] : g->s->first_mb + i;
 	int availA, availB;
+	int64_t ia = (int64_t)i - 1, ib = (int64_t)i - (int64_t)g->W;
 	uint32_t nA = 0, nB = 0, x, y, bw4, bh4;
 	const uint8_t *cur = g->nz + (size_t)i * 48 + comp * 16;
+	if (g->addr_of) {
+		/* a neighbour counts when it is part of this slice and came
+		 * before (6.4.8: same slice, smaller address) */
+		ia = addr >= 1 ? g->idx_of[addr - 1] : -1;
+		ib = addr >= g->W ? g->idx_of[addr - g->W] : -1;
+	}
 	static const uint8_t lx[16] = {0, 1, 0, 1, 2, 3, 2, 3,
 				       0, 1, 0, 1, 2, 3, 2, 3};
 	static const uint8_t ly[16] = {0, 0, 1, 1, 0, 0, 1, 1,
@@ -422,9 +611,9 @@ static uint32_t neighbour_nc(struct gen *g, uint32_t i, uint32_t comp,
 		availA = 1;
 		nA = chroma ? cur[2 * y + x - 1] : cur[lidx[y][x - 1]];
 	} else {
-		availA = (addr % g->W != 0) && i >= 1;
+		availA = (addr % g->W != 0) && ia >= 0;
 		if (availA) {
-			const uint8_t *l = cur - 48;
+			const uint8_t *l = g->nz + (size_t)ia * 48 + comp * 16;
 			nA = chroma ? l[2 * y + bw4 - 1] : l[lidx[y][bw4 - 1]];
 		}
 	}
@@ -433,9 +622,9 @@ static uint32_t neighbour_nc(struct gen *g, uint32_t i, uint32_t comp,
 		availB = 1;
 		nB = chroma ? cur[2 * (y - 1) + x] : cur[lidx[y - 1][x]];
 	} else {
-		availB = i >= g->W;
+		availB = ib >= 0;
 		if (availB) {
-			const uint8_t *t = cur - (size_t)48 * g->W;
+			const uint8_t *t = g->nz + (size_t)ib * 48 + comp * 16;
 			nB = chroma ? t[2 * (bh4 - 1) + x] : t[lidx[bh4 - 1][x]];
 		}
 	}
@@ -1034,6 +1223,17 @@ static void put_slice_header(struct gen *g)
 			bw_se(w, s->beta_offset_div2);
 		}
 	}
+	if (c->num_slice_groups_minus1 > 0 && c->slice_group_map_type >= 3 &&
+	    c->slice_group_map_type <= 5) {
+		/* Ceil(Log2(PicSizeInMapUnits / SliceGroupChangeRate + 1)) bits */
+		uint32_t v = c->width_mbs * c->height_mbs /
+				     (c->slice_group_change_rate_minus1 + 1u) + 1u;
+		uint32_t bits = 0;
+		while (bits < 32 && (1ull << bits) < v)
+			bits++;
+		if (bits)
+			bw_u_wide(w, s->slice_group_change_cycle, bits);
+	}
 }
 
 size_t h264gen_slice_bound(const struct h264gen_cfg *cfg,
@@ -1095,6 +1295,44 @@ int h264gen_slice_nal(const struct h264gen_cfg *cfg,
 	g.nz = calloc((size_t)sl->num_mbs, 48);
 	if (g.nz == NULL)
 		return -ENOMEM;
+	if (cfg->num_slice_groups_minus1 > 0) {
+		/* the slice codes macroblocks of first_mb's group, in address
+		 * order (8.2.2: nextMbAddress) */
+		uint32_t units = cfg->width_mbs * cfg->height_mbs;
+		uint32_t total = (cfg->field_coding && !sl->field_pic) ? 2u * units
+								       : units;
+		uint8_t *map = malloc(total ? total : 1);
+		uint32_t a, k = 0;
+		long nm;
+		g.addr_of = malloc((size_t)sl->num_mbs * sizeof(uint32_t));
+		g.idx_of = malloc((size_t)(total ? total : 1) * sizeof(int32_t));
+		nm = map ? h264gen_mb_to_slice_group_map(
+				   cfg, sl->slice_group_change_cycle,
+				   sl->field_pic, map, total)
+			 : -ENOMEM;
+		if (nm < 0 || !g.addr_of || !g.idx_of || sl->first_mb >= total) {
+			free(map);
+			free(g.addr_of);
+			free(g.idx_of);
+			free(g.nz);
+			return nm < 0 ? (int)nm : -EINVAL;
+		}
+		for (a = 0; a < total; a++)
+			g.idx_of[a] = -1;
+		for (a = sl->first_mb; a < total && k < sl->num_mbs; a++)
+			if (map[a] == map[sl->first_mb]) {
+				g.idx_of[a] = (int32_t)k;
+				g.addr_of[k++] = a;
+			}
+		free(map);
+		if (k != sl->num_mbs) { /* the group has fewer macroblocks left */
+			free(g.addr_of);
+			free(g.idx_of);
+			free(g.nz);
+			return -ERANGE;
+		}
+		g.n_addr = total;
+	}
 	if (t2)
 		memset(t2, 0, (size_t)sl->num_mbs * t2_stride);
 	for (i = 0; i < sl->num_mbs; i++) {
@@ -1131,6 +1369,8 @@ int h264gen_slice_nal(const struct h264gen_cfg *cfg,
 	}
 	bw_trailing(&g.w);
 	free(g.nz);
+	free(g.addr_of);
+	free(g.idx_of);
 	return finish(&g.w);
 }
 

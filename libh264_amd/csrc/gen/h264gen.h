@@ -49,6 +49,16 @@ struct h264gen_cfg {
 	 * mb_adaptive_frame_field_flag = 1 */
 	uint32_t field_coding;
 	uint32_t delta_pic_order_always_zero_flag; /* pic_order_cnt_type 1 */
+	/* slice groups (FMO, 7.3.2.2 / 8.2.2); num_slice_groups_minus1 = 0: none.
+	 * A slice then codes macroblocks of ONE slice group: first_mb picks the
+	 * group, num_mbs counts that group's macroblocks from there on. */
+	uint32_t num_slice_groups_minus1; /* <= 7 */
+	uint32_t slice_group_map_type; /* 0..6 */
+	uint32_t run_length_minus1[8]; /* type 0 */
+	uint32_t top_left[8], bottom_right[8]; /* type 2 */
+	uint32_t slice_group_change_direction_flag; /* types 3..5 */
+	uint32_t slice_group_change_rate_minus1;
+	uint8_t slice_group_id[256]; /* type 6: pictures of <= 256 map units */
 };
 
 #define H264GEN_HDR_RPLM 0x1 /* ref_pic_list_modification entries */
@@ -76,6 +86,8 @@ struct h264gen_slice {
 	uint32_t end_with_skip; /* finish a P/B slice on an mb_skip_run */
 	uint32_t cabac_payload; /* CABAC PPS: bytes of opaque slice data */
 	uint32_t field_pic; /* field_coding != 0: 0 frame picture, 1 top, 2 bottom field */
+	uint32_t slice_group_change_cycle; /* slice group map types 3..5 */
+	uint32_t reserved0;
 	uint64_t seed;
 };
 
@@ -101,6 +113,15 @@ int h264gen_slice_nal(const struct h264gen_cfg *cfg,
 long h264gen_batch(const struct h264gen_cfg *cfg,
 		   const struct h264gen_slice *slices, uint32_t n, int threads,
 		   uint8_t *out, size_t cap, uint64_t *offs, uint32_t *sizes);
+
+/* The macroblock-to-slice-group map of a picture (8.2.2.1 - 8.2.2.8, written
+ * from the standard), one byte per macroblock address of a picture coded as
+ * `field_pic` (see struct h264gen_slice); returns the number of macroblocks
+ * or -errno.  For building slices: the addresses of group g from `first` on
+ * are those with map[a] == g, a >= first. */
+long h264gen_mb_to_slice_group_map(const struct h264gen_cfg *cfg,
+				   uint32_t slice_group_change_cycle,
+				   uint32_t field_pic, uint8_t *map, size_t cap);
 
 /* Worst-case size of one slice NAL for a config (for sizing `cap`). */
 size_t h264gen_slice_bound(const struct h264gen_cfg *cfg,

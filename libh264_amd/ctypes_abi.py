@@ -334,7 +334,13 @@ class GenCfg(S):
             "redundant_pic_cnt_present_flag "
             "bottom_field_pic_order_in_frame_present_flag "
             "constrained_intra_pred_flag vui field_coding "
-            "delta_pic_order_always_zero_flag").split()])
+            "delta_pic_order_always_zero_flag "
+            "num_slice_groups_minus1 slice_group_map_type").split()] +
+        [("run_length_minus1", u32 * 8), ("top_left", u32 * 8),
+         ("bottom_right", u32 * 8),
+         ("slice_group_change_direction_flag", u32),
+         ("slice_group_change_rate_minus1", u32),
+         ("slice_group_id", C.c_uint8 * 256)])
 
 
 class GenSlice(S):
@@ -347,7 +353,8 @@ class GenSlice(S):
             "num_ref_idx_l0_minus1 num_ref_idx_l1_minus1 cabac_init_idc "
             "hdr_extras pm_i16x16 pm_pcm pm_skip pm_intra_in_inter pm_t8x8 "
             "pm_escape pm_zero_pcm density pm_cbp_zero end_with_skip "
-            "cabac_payload field_pic").split()] +
+            "cabac_payload field_pic slice_group_change_cycle "
+            "reserved0").split()] +
         [("seed", u64)])
 
 

@@ -31,6 +31,9 @@ def lib():
         L.h264gen_batch.argtypes = [C.POINTER(GenCfg), C.c_void_p, C.c_uint32,
                                     C.c_int, C.c_void_p, C.c_size_t,
                                     C.c_void_p, C.c_void_p]
+        L.h264gen_mb_to_slice_group_map.restype = C.c_long
+        L.h264gen_mb_to_slice_group_map.argtypes = [
+            C.POINTER(GenCfg), C.c_uint32, C.c_uint32, C.c_void_p, C.c_size_t]
         L.h264gen_slice_bound.restype = C.c_size_t
         L.h264gen_slice_bound.argtypes = [C.POINTER(GenCfg),
                                           C.POINTER(GenSlice)]
@@ -99,6 +102,32 @@ def slice_nal(cfg, sl, want_t2=False):
                                                                stride)
         return out.raw[:r], exp
     return out.raw[:r]
+
+
+def slice_group_map(cfg, change_cycle=0, field_pic=0):
+    """macroblock-to-slice-group map of a picture as the generator derives it
+    from the standard (one uint8 per macroblock address)"""
+    cap = 2 * cfg.width_mbs * cfg.height_mbs + 16
+    buf = np.zeros(cap, dtype=np.uint8)
+    n = lib().h264gen_mb_to_slice_group_map(
+        C.byref(cfg), change_cycle, field_pic,
+        buf.ctypes.data_as(C.c_void_p), cap)
+    if n < 0:
+        raise OSError(-n, os.strerror(-n))
+    return buf[:n].copy()
+
+
+def group_slices(cfg, change_cycle=0, field_pic=0, split=1):
+    """(first_mb, num_mbs, addresses) for slices that together code every
+    macroblock of the picture: each slice group in `split` pieces."""
+    m = slice_group_map(cfg, change_cycle, field_pic)
+    out = []
+    for g in sorted(set(m.tolist())):
+        addrs = np.nonzero(m == g)[0]
+        for part in np.array_split(addrs, min(split, len(addrs))):
+            if len(part):
+                out.append((int(part[0]), len(part), part.astype(np.int64)))
+    return out
 
 
 def batch(cfg, slices, threads=None):

@@ -179,6 +179,8 @@ struct orc_ctx {
 			struct orc_mb_info *info;
 			size_t len, maxlen;
 		} mb_table;
+		uint32_t *group_map; /* ref src/h264_priv.h:109-110 */
+		uint32_t group_map_maxlen;
 		struct h264_nalu_header prev_slice_nalu_hdr;
 		struct h264_slice_header prev_slice_hdr;
 	} slice;
@@ -285,6 +287,10 @@ int orc_get_info_from_ps(const struct h264_sps *sps,
 			 struct h264_info *info);
 int orc_sei_update_internal_buf(struct h264_sei *sei);
 uint32_t orc_intlog2(uint32_t x);
+/* orc_fmo.c (ref src/h264_fmo.c) */
+int orc_gen_slice_group_map(struct orc_ctx *ctx);
+void orc_clear_slice_group_map(struct orc_ctx *ctx);
+uint32_t orc_next_mb_addr(struct orc_ctx *ctx, uint32_t mbAddr);
 
 /* ---- syntax (orc_syntax.c; ref src/h264_syntax.h) --------------------- */
 int orc_read_nalu_header(struct h264_bitstream *bs, struct h264_nalu_header *nh);

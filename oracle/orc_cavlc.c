@@ -994,7 +994,7 @@ static int slice_data_internal(struct h264_bitstream *bs, struct orc_reader *rd)
 			return orc_cabac_subset_slice_data(bs, rd);
 		return 0;
 	}
-	if (ctx->derived.MbaffFrameFlag || ctx->pps->num_slice_groups_minus1 > 0)
+	if (ctx->derived.MbaffFrameFlag)
 		return H264_AMD_E_UNSUPPORTED;
 	/* deviation shared with the product (h264_amd.h): the reference takes
 	 * any width and divides by a width of 0 */
@@ -1005,6 +1005,7 @@ static int slice_data_internal(struct h264_bitstream *bs, struct orc_reader *rd)
 	if (rd->cbs.slice_data_begin)
 		rd->cbs.slice_data_begin(ctx, sh, rd->userdata);
 	orc_clear_macroblock_table(ctx);
+	orc_gen_slice_group_map(ctx); /* status ignored, ref :723 */
 	addr = sh->first_mb_in_slice;
 	do {
 		if (ctx->slice.type != H264_SLICE_TYPE_I &&
@@ -1022,7 +1023,7 @@ static int slice_data_internal(struct h264_bitstream *bs, struct orc_reader *rd)
 							      ctx->mb->mbAddr,
 							      ctx->mb->mb_type,
 							      rd->userdata);
-				addr++;
+				addr = orc_next_mb_addr(ctx, addr);
 				mb_count++;
 			}
 			if (skip_run > 0 && !orc_bs_more_rbsp_data(bs))
@@ -1037,7 +1038,7 @@ static int slice_data_internal(struct h264_bitstream *bs, struct orc_reader *rd)
 		if (rd->cbs.slice_data_mb)
 			rd->cbs.slice_data_mb(ctx, sh, ctx->mb->mbAddr,
 					      ctx->mb->mb_type, rd->userdata);
-		addr++;
+		addr = orc_next_mb_addr(ctx, addr);
 		mb_count++;
 	} while (orc_bs_more_rbsp_data(bs));
 

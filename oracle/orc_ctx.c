@@ -84,7 +84,7 @@ int orc_get_sps_derived(const struct h264_sps *sps, struct h264_sps_derived *d)
 	return 0;
 }
 
-/* ref src/h264_ctx.c:81-124 (FMO map generation omitted: out of scope) */
+/* ref src/h264_ctx.c:81-124 */
 static void update_derived_slice(struct orc_ctx *ctx)
 {
 	const struct h264_sps *sps = ctx->sps;
@@ -118,6 +118,8 @@ static void update_derived_slice(struct orc_ctx *ctx)
 		ORC_MIN(sh->slice_group_change_cycle *
 				ctx->derived.SliceGroupChangeRate,
 			ctx->sps_derived.PicSizeInMapUnits);
+	if (pps->num_slice_groups_minus1 > 0)
+		orc_gen_slice_group_map(ctx); /* status ignored, ref :122-123 */
 }
 
 static void update_derived_sps(struct orc_ctx *ctx)
@@ -221,6 +223,7 @@ int orc_ctx_clear_slice(struct orc_ctx *ctx)
 	ctx->slice.rawdata.buf = NULL;
 	ctx->slice.rawdata.len = 0;
 	orc_clear_macroblock_table(ctx);
+	orc_clear_slice_group_map(ctx);
 	memset(&ctx->_mb, 0, sizeof(ctx->_mb));
 	ctx->mb = NULL;
 	update_derived_slice(ctx);
@@ -255,6 +258,7 @@ int orc_ctx_clear(struct orc_ctx *ctx)
 	for (i = 0; i < 256; i++)
 		free(ctx->pps_table[i]);
 	free(ctx->slice.mb_table.info);
+	free(ctx->slice.group_map);
 	memset(ctx, 0, sizeof(*ctx));
 	return 0;
 }

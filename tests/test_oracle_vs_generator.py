@@ -128,3 +128,80 @@ def test_pic_order_cnt_type_1(always_zero, field_coding):
     for h, s in zip(rec.headers, slices):
         if s.field_pic:
             assert h.delta_pic_order_cnt[1] == 0
+
+
+FMO_CASES = {
+    0: dict(num_slice_groups_minus1=2, run_length=(3, 0, 6)),
+    1: dict(num_slice_groups_minus1=3),
+    2: dict(num_slice_groups_minus1=2, top_left=(9, 20), bottom_right=(29, 38)),
+    3: dict(num_slice_groups_minus1=1, dirflag=0, rate=3, cycle=5),
+    "3r": dict(num_slice_groups_minus1=1, dirflag=1, rate=5, cycle=4, mtype=3),
+    4: dict(num_slice_groups_minus1=1, dirflag=1, rate=7, cycle=3),
+    5: dict(num_slice_groups_minus1=1, dirflag=0, rate=4, cycle=6),
+    6: dict(num_slice_groups_minus1=4, ids=lambda i: (i * 7 + i // 5) % 5),
+}
+
+
+def fmo_cfg(case, **kw):
+    """small_cfg with slice groups as FMO_CASES[case] says"""
+    c = FMO_CASES[case]
+    cfg = streams.small_cfg(**kw)
+    cfg.num_slice_groups_minus1 = c["num_slice_groups_minus1"]
+    cfg.slice_group_map_type = c.get("mtype", case)
+    for i, v in enumerate(c.get("run_length", ())):
+        cfg.run_length_minus1[i] = v
+    for i, v in enumerate(c.get("top_left", ())):
+        cfg.top_left[i] = v
+    for i, v in enumerate(c.get("bottom_right", ())):
+        cfg.bottom_right[i] = v
+    cfg.slice_group_change_direction_flag = c.get("dirflag", 0)
+    cfg.slice_group_change_rate_minus1 = c.get("rate", 1) - 1
+    if "ids" in c:
+        for i in range(cfg.width_mbs * cfg.height_mbs):
+            cfg.slice_group_id[i] = c["ids"](i)
+    return cfg, c.get("cycle", 0)
+
+
+def fmo_slices(cfg, cycle, seed0, split=2, field_pic=0):
+    out = []
+    for k, (first, n, addrs) in enumerate(
+            gen.group_slices(cfg, cycle, field_pic, split)):
+        s = streams.rich_slice(cfg, seed0 + k, (2, 0, 1)[k % 3], first, n,
+                               slice_group_change_cycle=cycle,
+                               field_pic=field_pic)
+        out.append((s, addrs))
+    return out
+
+
+@pytest.mark.parametrize("case", list(FMO_CASES))
+def test_slice_groups(case):
+    """FMO: every slice group map type (8.2.2.1 - 8.2.2.7).  The generator
+    derives the map from the standard, picks the macroblock addresses of each
+    slice from it and codes them with its own neighbour rule (same slice,
+    earlier address); the oracle follows the reference (src/h264_fmo.c,
+    src/h264_macroblock.c:306-351).  Records AND the address of every
+    slice_data_mb callback must agree."""
+    cfg, cycle = fmo_cfg(case)
+    pairs = fmo_slices(cfg, cycle, 500)
+    assert len(pairs) >= 2 * (cfg.num_slice_groups_minus1 + 1) - 1
+    rec = roundtrip(cfg, [s for s, _ in pairs])
+    mb_events = [e for e in rec.event_tuples() if e[0] == 7]
+    want = np.concatenate([a for _, a in pairs])
+    assert [e[1] for e in mb_events] == want.tolist()
+    # the picture is covered exactly once
+    assert sorted(want.tolist()) == list(range(cfg.width_mbs *
+                                               cfg.height_mbs))
+
+
+@pytest.mark.parametrize("field_pic", [0, 1, 2])
+def test_slice_groups_interlaced(field_pic):
+    """map units of interlaced material (8.2.2.8): a frame picture's unit
+    covers two macroblock rows, a field picture's one macroblock"""
+    cfg, cycle = fmo_cfg(1, field_coding=1)
+    pairs = fmo_slices(cfg, cycle, 600, field_pic=field_pic)
+    rec = roundtrip(cfg, [s for s, _ in pairs])
+    mb_events = [e for e in rec.event_tuples() if e[0] == 7]
+    want = np.concatenate([a for _, a in pairs])
+    assert [e[1] for e in mb_events] == want.tolist()
+    n = cfg.width_mbs * cfg.height_mbs * (1 if field_pic else 2)
+    assert sorted(want.tolist()) == list(range(n))
