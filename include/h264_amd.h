@@ -403,6 +403,18 @@ H264_API int h264_amd_last_kernel_ms(struct h264_amd_engine *eng,
 				     const char *family,
 				     float *ms);
 
+/* Slice groups (FMO): h264_amd_decode_slices() builds the macroblock-to-slice-
+ * group map of 8.2.2 per slice (the kernel needs it to find a slice's next
+ * macroblock address, ref src/h264_fmo.c:307-319).  Macroblock records are in
+ * slice order and carry no address; a caller that needs the addresses of a
+ * slice under a PPS with slice groups fetches that slice's map -- one byte per
+ * macroblock address of the picture, `size` <= PicSizeInMbs -- and walks it:
+ * the next address of the same group above the current one.  `index`: the
+ * slice's position in the LAST decode launch of this engine.  -ERANGE when
+ * that launch built no map for it. */
+H264_API int h264_amd_slice_group_map(struct h264_amd_engine *e, uint32_t index,
+				      uint8_t *dst, size_t size);
+
 /* ---- calibration and identification ---------------------------------------- */
 
 /* Time one pure streaming read of d_buf[0 .. len) with the scan kernel's work

@@ -76,6 +76,8 @@ struct h264_amd_params {
 	std::vector<h264_pps> pps_full;
 	std::vector<dev_sps> sps;
 	std::vector<dev_pps> pps;
+	std::vector<dev_fmo> fmo; /* parallel to pps */
+	uint32_t n_fmo; /* PPS versions with slice groups */
 	std::vector<dev_epoch> epochs;
 	uint64_t serial; /* bumped on every change */
 	uint32_t max_width_mbs, max_pic_mbs;
@@ -92,8 +94,12 @@ struct h264_amd_engine {
 	uint64_t params_serial;
 	dev_sps *d_sps;
 	dev_pps *d_pps;
+	dev_fmo *d_fmo;
 	dev_epoch *d_epochs;
-	size_t cap_sps, cap_pps, cap_epochs;
+	size_t cap_sps, cap_pps, cap_fmo, cap_epochs;
+	uint8_t *d_fmo_map; /* per-slice macroblock-to-slice-group maps */
+	size_t cap_fmo_map;
+	uint32_t fmo_stride, fmo_n; /* of the last decode launch */
 	hipEvent_t ev[FAM_COUNT][2];
 	bool timed[FAM_COUNT];
 	/* scan scratch */
@@ -280,6 +286,8 @@ extern "C" int h264_amd_engine_destroy(struct h264_amd_engine *e)
 	hipFree(e->d_cabac);
 	hipFree(e->d_sps);
 	hipFree(e->d_pps);
+	hipFree(e->d_fmo);
+	hipFree(e->d_fmo_map);
 	hipFree(e->d_epochs);
 	scan_scratch_free(&e->scan);
 	hipFree(e->d_avcc_nals);
@@ -409,6 +417,8 @@ extern "C" int h264_amd_params_reset(struct h264_amd_params *p)
 	p->pps_full.clear();
 	p->sps.clear();
 	p->pps.clear();
+	p->fmo.clear();
+	p->n_fmo = 0;
 	p->epochs.clear();
 	dev_epoch e0;
 	memset(&e0, 0xff, sizeof(e0)); /* every id: DEV_NO_VERSION */
@@ -502,8 +512,24 @@ extern "C" int h264_amd_params_put_pps(struct h264_amd_params *p,
 	d.num_ref_idx_l1_default_active_minus1 =
 		pps->num_ref_idx_l1_default_active_minus1;
 	d.slice_group_change_rate_minus1 = pps->slice_group_change_rate_minus1;
+	dev_fmo f;
+	memset(&f, 0, sizeof(f));
+	if (pps->num_slice_groups_minus1 > 0) {
+		f.slice_group_change_direction_flag =
+			pps->slice_group_change_direction_flag != 0;
+		f.pic_size_in_map_units_minus1 = pps->pic_size_in_map_units_minus1;
+		for (int i = 0; i < 8; i++) {
+			f.run_length_minus1[i] = pps->run_length_minus1[i];
+			f.top_left[i] = pps->top_left[i];
+			f.bottom_right[i] = pps->bottom_right[i];
+		}
+		for (int i = 0; i < 256; i++)
+			f.slice_group_id[i] = DEV_SAT8(pps->slice_group_id[i]);
+		p->n_fmo++;
+	}
 	p->pps_full.push_back(*pps);
 	p->pps.push_back(d);
+	p->fmo.push_back(f);
 	dev_epoch ne = cur;
 	ne.pps_ver[pps->pic_parameter_set_id] = (uint16_t)(p->pps.size() - 1);
 	p->epochs.push_back(ne);
@@ -539,11 +565,29 @@ static int sync_params(h264_amd_engine *e, const h264_amd_params *p)
 		return r;
 	if ((r = upload_vec(&e->d_pps, &e->cap_pps, p->pps, e->stream)) < 0)
 		return r;
+	if ((r = upload_vec(&e->d_fmo, &e->cap_fmo, p->fmo, e->stream)) < 0)
+		return r;
 	if ((r = upload_vec(&e->d_epochs, &e->cap_epochs, p->epochs, e->stream)) < 0)
 		return r;
 	HIP_TRY(hipStreamSynchronize(e->stream));
 	e->params_src = p;
 	e->params_serial = p->serial;
+	return 0;
+}
+
+/* the macroblock-to-slice-group map the last h264_amd_decode_slices() launch
+ * built for slice `index` of that launch */
+extern "C" int h264_amd_slice_group_map(struct h264_amd_engine *e, uint32_t index,
+					uint8_t *dst, size_t size)
+{
+	if (e == NULL || dst == NULL)
+		return -EINVAL;
+	if (index >= e->fmo_n || size > e->fmo_stride)
+		return -ERANGE;
+	HIP_TRY(hipSetDevice(e->device));
+	HIP_TRY(hipMemcpyAsync(dst, e->d_fmo_map + (size_t)index * e->fmo_stride,
+			       size, hipMemcpyDeviceToHost, e->stream));
+	HIP_TRY(hipStreamSynchronize(e->stream));
 	return 0;
 }
 
@@ -623,6 +667,28 @@ extern "C" int h264_amd_decode_slices(struct h264_amd_engine *e,
 		a.row_pitch = params->max_width_mbs < H264_AMD_MAX_PIC_WIDTH_MBS
 				      ? params->max_width_mbs
 				      : H264_AMD_MAX_PIC_WIDTH_MBS;
+	/* slice groups: a macroblock-to-slice-group map per slice, built by the
+	 * kernel behind the slice header (types 3..5 depend on it) */
+	a.fmov = e->d_fmo;
+	if ((args->reader_flags & H264_READER_FLAGS_SLICE_DATA) &&
+	    params->n_fmo > 0) {
+		uint32_t stride = params->max_pic_mbs < DEV_FMO_MAX_MBS
+					  ? params->max_pic_mbs
+					  : DEV_FMO_MAX_MBS;
+		stride = (stride + 63u) & ~63u;
+		size_t want = (size_t)a.n * stride;
+		if (want > e->cap_fmo_map) {
+			hipFree(e->d_fmo_map);
+			e->d_fmo_map = NULL;
+			e->cap_fmo_map = 0;
+			HIP_TRY(hipMalloc((void **)&e->d_fmo_map, want));
+			e->cap_fmo_map = want;
+		}
+		a.fmo_map = e->d_fmo_map;
+		a.fmo_stride = stride;
+	}
+	e->fmo_stride = a.fmo_stride;
+	e->fmo_n = a.fmo_map ? a.n : 0;
 
 	{
 		uint32_t tail = SD_REC_BYTES + 16u * a.row_pitch;

@@ -400,9 +400,52 @@ static int retry_big_slice(struct h264_reader *rd, struct rd_batch *b,
 
 /* ---- step 4: replay -------------------------------------------------------- */
 
+/* Addresses of a slice's macroblocks under slice groups: the reference walks
+ * its map with h264_next_mb_addr (src/h264_fmo.c:307-319); the map is the one
+ * the kernel built for this slice (index `kidx` of the last launch). */
+static int slice_addresses(struct h264_reader *rd, uint32_t kidx,
+			   const struct h264_amd_slice_result *r, uint32_t **ret)
+{
+	struct h264_ctx *ctx = rd->ctx;
+	struct h264_amd_engine *eng;
+	uint32_t pic = ctx->derived.PicSizeInMbs, m, cur = r->first_mb_in_slice;
+	uint8_t *map;
+	uint32_t *addrs;
+	int res = h264_host_engine(&eng);
+	if (res < 0)
+		return res;
+	map = malloc(pic ? pic : 1);
+	addrs = malloc((r->mb_count ? r->mb_count : 1) * sizeof(*addrs));
+	if (map == NULL || addrs == NULL) {
+		free(map);
+		free(addrs);
+		return -ENOMEM;
+	}
+	res = h264_amd_slice_group_map(eng, kidx, map, pic);
+	if (res < 0) {
+		free(map);
+		free(addrs);
+		return res;
+	}
+	for (m = 0; m < r->mb_count; m++) {
+		uint32_t i = cur + 1;
+		addrs[m] = cur;
+		if (i < pic && cur < pic) {
+			uint8_t g = map[cur];
+			while (i < pic && map[i] != g)
+				i++;
+		}
+		cur = i;
+	}
+	free(map);
+	*ret = addrs;
+	return 0;
+}
+
 static int replay_slice(struct h264_reader *rd, const uint8_t *nal, size_t len,
 			const struct h264_amd_slice_result *r,
-			const struct h264_slice_header *sh, const uint32_t *t0)
+			const struct h264_slice_header *sh, const uint32_t *t0,
+			uint32_t kidx)
 {
 	struct h264_ctx *ctx = rd->ctx;
 	const struct h264_ctx_cbs *cbs = &rd->cbs;
@@ -436,10 +479,18 @@ static int replay_slice(struct h264_reader *rd, const uint8_t *nal, size_t len,
 		if (cbs->slice_data_begin)
 			cbs->slice_data_begin(ctx, &ctx->slice.hdr, rd->userdata);
 		if (cbs->slice_data_mb) {
+			uint32_t *addrs = NULL;
+			if (ctx->pps->num_slice_groups_minus1 > 0) {
+				int res = slice_addresses(rd, kidx, r, &addrs);
+				if (res < 0)
+					return res;
+			}
 			for (m = 0; m < r->mb_count; m++)
 				cbs->slice_data_mb(ctx, &ctx->slice.hdr,
-						   r->first_mb_in_slice + m,
+						   addrs ? addrs[m]
+							 : r->first_mb_in_slice + m,
 						   t0[m] & 0xffu, rd->userdata);
+			free(addrs);
 		}
 		if (r->status < 0)
 			return r->status;
@@ -489,7 +540,7 @@ static int replay_nal(struct h264_reader *rd, struct rd_batch *b,
 		size_t k;
 		if (hs != NULL) {
 			/* header parsed on the host (slicehdr.c) */
-			res = replay_slice(rd, nal, len, &hs->r, &hs->sh, NULL);
+			res = replay_slice(rd, nal, len, &hs->r, &hs->sh, NULL, 0);
 			if (res < 0)
 				return res;
 			if (cbs->slice)
@@ -505,13 +556,19 @@ static int replay_nal(struct h264_reader *rd, struct rd_batch *b,
 		r = &rd->h_results[k];
 		t0 = b->tier == H264_AMD_TIER_T0 ? rd->h_mb + k * b->mb_cap
 						 : NULL;
+		uint32_t kidx = (uint32_t)k;
 		if (r->status == H264_AMD_E_MB_OVERFLOW) {
 			res = retry_big_slice(rd, b, (size_t)slice, &big, &t0);
 			if (res < 0)
 				return res;
 			r = &big;
+			kidx = 0; /* decoded again on its own */
+			/* that launch replaced the engine's per-slice scratch
+			 * (slice group maps): the chunk is fetched again for
+			 * the slices behind this one */
+			b->hi = b->lo;
 		}
-		res = replay_slice(rd, nal, len, r, &rd->h_headers[k], t0);
+		res = replay_slice(rd, nal, len, r, &rd->h_headers[k], t0, kidx);
 		if (res < 0)
 			return res;
 		if (cbs->slice)

@@ -62,6 +62,23 @@ struct dev_pps {
 	uint32_t slice_group_change_rate_minus1;
 };
 
+/* slice-group fields of a PPS (7.3.2.2), one record per PPS version next to
+ * its dev_pps; only read when num_slice_groups_minus1 > 0.  Values are kept
+ * in full: the map builders bound every use (kernels/slice_decode.hip,
+ * sd_fmo_build). */
+struct dev_fmo {
+	uint32_t slice_group_change_direction_flag;
+	uint32_t pic_size_in_map_units_minus1;
+	uint32_t run_length_minus1[8];
+	uint32_t top_left[8];
+	uint32_t bottom_right[8];
+	uint8_t slice_group_id[256];
+};
+/* largest picture (macroblocks of a frame) the per-slice map scratch is sized
+ * for: level 6.2 allows 139264; beyond it slices of a picture with slice
+ * groups answer H264_AMD_E_UNSUPPORTED */
+#define DEV_FMO_MAX_MBS 139264u
+
 /* which version every id names during one epoch */
 struct dev_epoch {
 	uint16_t pps_ver[256];

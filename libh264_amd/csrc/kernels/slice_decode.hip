@@ -34,7 +34,9 @@
  * top-row nz context.  Cost model and measurements:
  * profiles/r01_decode_cost_model.md.
  *
- * Out of scope (status H264_AMD_E_UNSUPPORTED): MBAFF frames and slice groups.
+ * Slice groups (FMO): the map of 8.2.2 is built per slice by sd_fmo_build and
+ * walked by sd_fmo_next (ref src/h264_fmo.c).
+ * Out of scope (status H264_AMD_E_UNSUPPORTED): MBAFF frames.
  */
 #include <hip/hip_runtime.h>
 #include <errno.h>
@@ -71,6 +73,10 @@ struct SliceState {
 	/* parameter sets */
 	uint32_t cat, W, bdl, bdc, pcm_chroma;
 	uint32_t t8x8_mode, direct8x8, entropy, unsupported;
+	/* slice groups */
+	uint32_t fmo; /* num_slice_groups_minus1 (0: none) */
+	uint32_t fmo_type, pps_version, frame_mbs_only, map_units_h;
+	uint32_t change_cycle, change_rate;
 	/* header */
 	uint32_t slice_type, first_mb, nref0, nref1, field_pic;
 	int32_t slice_qp;
@@ -459,13 +465,197 @@ sd_slice_header(WaveBits &wb, uint32_t lane, uint8_t *stage, SliceState &S,
 			units / (pps.slice_group_change_rate_minus1 + 1u) + 1u);
 		v = n ? wb_u(wb, lane, n) : 0u;
 		HP(slice_group_change_cycle, v);
+		S.change_cycle = v;
 	}
 	S.nref0 = nref0;
 	S.nref1 = nref1;
 	S.field_pic = field_pic;
-	S.unsupported = (sps.mb_adaptive_frame_field_flag && !field_pic) ||
-			pps.num_slice_groups_minus1 > 0;
+	S.fmo = pps.num_slice_groups_minus1;
+	S.fmo_type = pps.slice_group_map_type;
+	S.pps_version = pv;
+	S.frame_mbs_only = sps.frame_mbs_only_flag;
+	S.map_units_h = sps.pic_height_in_map_units;
+	S.change_rate = pps.slice_group_change_rate_minus1 + 1u;
+	S.unsupported = sps.mb_adaptive_frame_field_flag && !field_pic;
 	return 0;
+}
+
+/* ---- slice groups (ref src/h264_fmo.c:33-319) ------------------------------
+ * The macroblock-to-slice-group map of the picture, one byte per macroblock
+ * ADDRESS, written to this slice's piece of the map scratch in HBM behind the
+ * slice header (types 3..5 depend on slice_group_change_cycle).  The map units
+ * of 8.2.2.1 - 8.2.2.7 are laid out over the lanes; 8.2.2.8 (map unit ->
+ * macroblock) is folded in.  Box-out (type 3) is a walk with memory: it runs
+ * on a one-bit-per-unit image in LDS (the header staging area, free by now),
+ * every lane following the same steps.  Where the reference indexes without
+ * bounds the choices are the oracle's (oracle/orc_fmo.c): cells outside the
+ * map are skipped, ids past the PPS's 256 are group 0.
+ * Returns 0 or H264_AMD_E_UNSUPPORTED (picture too large for the scratch /
+ * the LDS image). */
+#define SD_FMO_LDS_UNITS (SD_STAGE_BYTES * 8u)
+
+/* slice group of one map unit, per lane, without a divergent branch (see the
+ * note on divergent branches above: loops and switches here are uniform, what
+ * differs between lanes is selected) */
+__device__ __forceinline__ uint32_t sd_fmo_unit_group(const dev_fmo *f,
+						      const SliceState &S,
+						      uint32_t unit, uint32_t n,
+						      uint32_t W, uint32_t units0)
+{
+	const uint32_t G = S.fmo + 1u;
+	const uint32_t dir = f->slice_group_change_direction_flag;
+	const uint32_t upper = dir ? n - units0 : units0;
+	uint32_t res = 0;
+	if (S.fmo_type == 0) {
+		/* interleaved: runs repeat with period sum(run_length + 1) */
+		uint64_t period = 0, acc = 0, pos;
+		for (uint32_t g = 0; g < 8u; g++)
+			period += g < G ? (uint64_t)f->run_length_minus1[g] + 1u : 0u;
+		pos = unit % period;
+		for (uint32_t g = 0; g < 8u; g++) {
+			uint64_t run = g < G ? (uint64_t)f->run_length_minus1[g] + 1u
+					     : 0u;
+			res = (pos >= acc && pos < acc + run) ? g : res;
+			acc += run;
+		}
+	} else if (S.fmo_type == 1) {
+		res = ((unit % W) + (((unit / W) * G) / 2u)) % G;
+	} else if (S.fmo_type == 2) {
+		uint32_t x = unit % W, y = unit / W;
+		res = G - 1u;
+		for (uint32_t k = 0; k < 7u; k++) {
+			/* groups G - 2 down to 0: a lower one overrides */
+			uint32_t g = 6u - k;
+			uint32_t yt = f->top_left[g] / W, xl = f->top_left[g] % W;
+			uint32_t yb = f->bottom_right[g] / W;
+			uint32_t xr = f->bottom_right[g] % W;
+			bool in = g + 1u < G && y >= yt && y <= yb && x >= xl &&
+				  x <= xr;
+			res = in ? g : res;
+		}
+	} else if (S.fmo_type == 4) {
+		res = unit < upper ? dir : 1u - dir;
+	} else if (S.fmo_type == 5) {
+		uint32_t H = n / W;
+		uint32_t k = (unit % W) * H + unit / W;
+		res = k < upper ? dir : 1u - dir;
+	} else if (S.fmo_type == 6) {
+		uint32_t have = f->pic_size_in_map_units_minus1 < 255u
+					? f->pic_size_in_map_units_minus1 + 1u
+					: 256u;
+		uint32_t id = f->slice_group_id[unit & 255u];
+		res = unit < have ? id : 0u;
+	}
+	return res;
+}
+
+__device__ __forceinline__ int sd_fmo_build(const dev_fmo *f, const SliceState &S,
+					    uint8_t *stage, uint8_t *map,
+					    uint32_t map_cap, uint32_t lane,
+					    uint32_t &pic_mbs)
+{
+	const uint32_t W = S.W;
+	const uint64_t n64 = (uint64_t)W * S.map_units_h;
+	const uint64_t mbs64 = (S.frame_mbs_only || S.field_pic) ? n64 : 2u * n64;
+	if (mbs64 > map_cap || n64 == 0)
+		return H264_AMD_E_UNSUPPORTED;
+	const uint32_t n = (uint32_t)n64, H = S.map_units_h;
+	pic_mbs = (uint32_t)mbs64;
+	/* MapUnitsInSliceGroup0 (ref src/h264_ctx.c:119-122) */
+	uint64_t u0 = (uint64_t)S.change_cycle * S.change_rate;
+	const uint32_t units0 = u0 < n ? (uint32_t)u0 : n;
+	uint32_t *bits = reinterpret_cast<uint32_t *>(stage);
+
+	if (S.fmo_type == 3) {
+		if (n > SD_FMO_LDS_UNITS)
+			return H264_AMD_E_UNSUPPORTED;
+		/* bit set = unit in group 0 */
+		for (uint32_t i = lane; i < SD_STAGE_BYTES / 4u; i += 64u)
+			bits[i] = 0;
+		const int32_t dir = (int32_t)f->slice_group_change_direction_flag;
+		int32_t x = (int32_t)((W - (uint32_t)dir) / 2u);
+		int32_t y = (int32_t)((H - (uint32_t)dir) / 2u);
+		int32_t left = x, top = y, right = x, bottom = y;
+		int32_t xd = dir - 1, yd = dir;
+		/* every vacant step fills a unit; steps over filled units are
+		 * bounded by the walk around the growing box */
+		uint32_t k = 0, guard = 8u * n + 64u;
+		while (k < units0 && guard-- > 0) {
+			uint32_t cell = (uint32_t)y * W + (uint32_t)x;
+			uint32_t word = wb_uniform(bits[cell >> 5]);
+			uint32_t bit = 1u << (cell & 31u);
+			if (!(word & bit)) {
+				bits[cell >> 5] = word | bit; /* all lanes, same */
+				k++;
+			}
+			if (xd == -1 && x == left) {
+				left = left > 0 ? left - 1 : 0;
+				x = left;
+				xd = 0;
+				yd = 2 * dir - 1;
+			} else if (xd == 1 && x == right) {
+				right = right + 1 < (int32_t)W - 1 ? right + 1
+								   : (int32_t)W - 1;
+				x = right;
+				xd = 0;
+				yd = 1 - 2 * dir;
+			} else if (yd == -1 && y == top) {
+				top = top > 0 ? top - 1 : 0;
+				y = top;
+				xd = 1 - 2 * dir;
+				yd = 0;
+			} else if (yd == 1 && y == bottom) {
+				bottom = bottom + 1 < (int32_t)H - 1 ? bottom + 1
+								     : (int32_t)H - 1;
+				y = bottom;
+				xd = 2 * dir - 1;
+				yd = 0;
+			} else {
+				x += xd;
+				y += yd;
+			}
+		}
+	}
+	/* one byte per macroblock address (8.2.2.8: map units are macroblocks
+	 * for frame_mbs_only and for field pictures; a frame picture of
+	 * interlaced material has two macroblock rows per unit row) */
+	for (uint32_t a0 = 0; a0 < pic_mbs; a0 += 64u) {
+		/* lanes past the end repeat the last macroblock's store */
+		uint32_t a = a0 + lane < pic_mbs ? a0 + lane : pic_mbs - 1u;
+		uint32_t unit = (S.frame_mbs_only || S.field_pic)
+					? a
+					: (a / (2u * W)) * W + (a % W);
+		uint32_t g3 = (bits[(unit >> 5) & (SD_STAGE_BYTES / 4u - 1u)] >>
+			       (unit & 31u)) & 1u ? 0u : 1u;
+		uint32_t g = S.fmo_type == 3
+				     ? g3
+				     : sd_fmo_unit_group(f, S, unit, n, W, units0);
+		map[a] = (uint8_t)g;
+	}
+	return 0;
+}
+
+/* h264_next_mb_addr (ref src/h264_fmo.c:307-319): the next address above `cur`
+ * of the same slice group, PicSizeInMbs if there is none, cur + 1 beyond the
+ * picture.  64 addresses per look. */
+__device__ __forceinline__ uint32_t sd_fmo_next(const uint8_t *map,
+						uint32_t pic_mbs, uint32_t cur,
+						uint32_t lane)
+{
+	uint32_t i = cur + 1u;
+	if (i >= pic_mbs)
+		return i;
+	const uint32_t g = wb_uniform(map[cur]);
+	for (;;) {
+		uint32_t a = i + lane;
+		uint32_t v = map[a < pic_mbs ? a : pic_mbs - 1u];
+		wb_mask_t hit = __ballot(a < pic_mbs && v == g);
+		if (hit)
+			return i + (uint32_t)__builtin_ctzll(hit);
+		i += 64u;
+		if (i >= pic_mbs)
+			return pic_mbs;
+	}
 }
 
 /* ---- macroblock bookkeeping ---------------------------------------------- */
@@ -1045,7 +1235,8 @@ template <bool ONLY_I>
 __device__ __forceinline__ int
 sd_slice_data(WaveBits &wb, const VlcTabs &vt, uint32_t cbp_map, uint32_t lane,
 	      uint8_t *stage, uint8_t *row, const SliceState &S, OutCtx &o,
-	      uint32_t mb_capacity, uint32_t &mb_count)
+	      uint32_t mb_capacity, uint32_t &mb_count, const uint8_t *fmo_map,
+	      uint32_t pic_mbs)
 {
 	const uint32_t cat = S.cat, W = S.W;
 	const bool is_si = !ONLY_I && S.slice_type == H264_SLICE_TYPE_SI;
@@ -1077,6 +1268,33 @@ sd_slice_data(WaveBits &wb, const VlcTabs &vt, uint32_t cbp_map, uint32_t lane,
 	sd_mb_consts(m, lane, cat);
 	uint32_t mbx = S.first_mb % W;
 	uint32_t mbidx = 0;
+	/* Slice groups (generic instantiation only).  The slice walks the
+	 * addresses of ONE group in increasing order, so "macroblock X is part
+	 * of this slice and came before" (the reference's available flag,
+	 * src/h264_macroblock.c:318-350) is: X is the previous address for the
+	 * left neighbour, and for the one above, the last address this slice
+	 * visited in that column (kept as a tag in the column's row context). */
+	const bool fmo = !ONLY_I && S.fmo != 0;
+	uint32_t cur_addr = S.first_mb, prev_addr = 0xffffffffu;
+	if (fmo) {
+		for (uint32_t c0 = 0; c0 < W; c0 += 64u) {
+			uint32_t c = c0 + lane < W ? c0 + lane : W - 1u;
+			*reinterpret_cast<uint32_t *>(row + 16u * c + 12u) =
+				0xffffffffu;
+		}
+	}
+/* one macroblock further: tags, addresses, column */
+#define SD_FMO_STEP()                                                          \
+	do {                                                                   \
+		if (fmo) {                                                     \
+			uint32_t col_ = cur_addr % W;                          \
+			*reinterpret_cast<uint32_t *>(row + 16u * col_ + 12u) = \
+				cur_addr;                                      \
+			prev_addr = cur_addr;                                  \
+			cur_addr = sd_fmo_next(fmo_map, pic_mbs, cur_addr, lane); \
+			mbx = cur_addr % W;                                    \
+		}                                                              \
+	} while (0)
 	/* field pictures: every macroblock carries the picture's flag
 	 * (ref src/h264_slice_data.c:1145-1149) */
 	const uint32_t field_flag = S.field_pic ? (uint32_t)H264_AMD_MB_FIELD : 0u;
@@ -1109,6 +1327,7 @@ sd_slice_data(WaveBits &wb, const VlcTabs &vt, uint32_t cbp_map, uint32_t lane,
 					return H264_AMD_E_MB_OVERFLOW;
 				sd_emit_skipped(o, skip_word0, mbidx, lane);
 				sd_next_mb(m, row, stage - SD_DUMP_BYTES, mbx, W, lane);
+				SD_FMO_STEP();
 				mbidx++;
 				mb_count = mbidx;
 			}
@@ -1121,6 +1340,12 @@ sd_slice_data(WaveBits &wb, const VlcTabs &vt, uint32_t cbp_map, uint32_t lane,
 		/* ---- new macroblock: neighbours, clean record ---- */
 		m.availA = (mbx != 0 && mbidx >= 1) ? 1u : 0u;
 		m.availB = mbidx >= W ? 1u : 0u;
+		if (fmo) {
+			uint32_t tag = wb_uniform(*reinterpret_cast<const uint32_t *>(
+				row + 16u * mbx + 12u));
+			m.availA = (mbx != 0 && prev_addr + 1u == cur_addr) ? 1u : 0u;
+			m.availB = (cur_addr >= W && tag == cur_addr - W) ? 1u : 0u;
+		}
 		sd_mb_begin(m, row, mbx, lane);
 		/* clean record: the staging area is 4 KiB, zero what the
 		 * largest record (1792 B) can touch */
@@ -1505,9 +1730,11 @@ sd_slice_data(WaveBits &wb, const VlcTabs &vt, uint32_t cbp_map, uint32_t lane,
 		}
 		sd_emit_staged(o, stage, mbidx, lane);
 		sd_next_mb(m, row, stage - SD_DUMP_BYTES, mbx, W, lane);
+		SD_FMO_STEP();
 		mbidx++;
 		mb_count = mbidx;
 	} while (wb_more_rbsp_data(wb, lane));
+#undef SD_FMO_STEP
 #undef VRD_UE
 #undef VRD_SE
 	return 0;
@@ -1529,6 +1756,11 @@ struct sd_args {
 	struct h264_slice_header *headers;
 	uint8_t *mb_out;
 	uint64_t buf_len; /* bytes behind buf, 0 = not checked */
+	/* slice groups: per PPS version the map parameters, and room for one
+	 * macroblock-to-slice-group map per slice (fmo_stride bytes each) */
+	const dev_fmo *fmov;
+	uint8_t *fmo_map;
+	uint32_t fmo_stride;
 	uint32_t row_pitch; /* macroblock columns of row context in LDS */
 	/* LDS of one wave: SD_STAGE_OFF + max(SD_STAGE_BYTES, SD_REC_BYTES + 16 *
 	 * row_pitch) */
@@ -1565,6 +1797,9 @@ __device__ __forceinline__ void sd_kernel_body(const sd_args &a)
 	S.bdl = S.bdc = 8;
 	S.pcm_chroma = 0;
 	S.t8x8_mode = S.direct8x8 = S.entropy = S.unsupported = 0;
+	S.fmo = S.fmo_type = S.pps_version = S.frame_mbs_only = 0;
+	S.map_units_h = S.change_cycle = 0;
+	S.change_rate = 1;
 	S.slice_type = 0;
 	S.first_mb = S.nref0 = S.nref1 = S.field_pic = 0;
 	S.slice_qp = 0;
@@ -1647,19 +1882,43 @@ __device__ __forceinline__ void sd_kernel_body(const sd_args &a)
 			} else if (S.W == 0 || S.W > a.row_pitch) {
 				status = H264_AMD_E_UNSUPPORTED;
 			} else {
-				rflags |= H264_AMD_SR_DATA_PARSED;
-				VlcTabs vt;
-				vlc_open(vt, lds_all, lane);
-				uint32_t cbp_map = a.vlc->cbp[lane];
-				if (S.slice_type == H264_SLICE_TYPE_I)
-					status = sd_slice_data<true>(
-						wb, vt, cbp_map, lane, stage, row, S, o,
-						a.mb_capacity, mb_count);
-				else
-					status = sd_slice_data<false>(
-						wb, vt, cbp_map, lane, stage, row, S, o,
-						a.mb_capacity, mb_count);
-				end_bit = wb_pos(wb);
+				/* slice groups: this slice's macroblock-to-slice-
+				 * group map first (the header image has left the
+				 * staging area, which the box-out walk borrows) */
+				uint8_t *fmo_map = nullptr;
+				uint32_t pic_mbs = 0;
+				if (S.fmo) {
+					if (a.fmo_map == nullptr || a.fmov == nullptr) {
+						status = H264_AMD_E_UNSUPPORTED;
+					} else {
+						fmo_map = a.fmo_map +
+							  (size_t)slice * a.fmo_stride;
+						status = sd_fmo_build(
+							a.fmov + S.pps_version, S, stage,
+							fmo_map, a.fmo_stride, lane,
+							pic_mbs);
+						/* the map is read back by this wave:
+						 * stores out, L1 refreshed */
+						__threadfence();
+					}
+				}
+				if (status == 0) {
+					rflags |= H264_AMD_SR_DATA_PARSED;
+					VlcTabs vt;
+					vlc_open(vt, lds_all, lane);
+					uint32_t cbp_map = a.vlc->cbp[lane];
+					if (S.slice_type == H264_SLICE_TYPE_I && !S.fmo)
+						status = sd_slice_data<true>(
+							wb, vt, cbp_map, lane, stage, row,
+							S, o, a.mb_capacity, mb_count,
+							nullptr, 0);
+					else
+						status = sd_slice_data<false>(
+							wb, vt, cbp_map, lane, stage, row,
+							S, o, a.mb_capacity, mb_count,
+							fmo_map, pic_mbs);
+					end_bit = wb_pos(wb);
+				}
 			}
 		}
 	}

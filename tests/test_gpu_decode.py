@@ -420,3 +420,57 @@ def test_descriptors_outside_the_buffer_are_answered_not_followed(engine):
                                                max(sizes) + 64)
     assert int(osizes[0]) == sizes[0] and int(osizes[5]) == sizes[2]
     assert all(int(osizes[i]) < 0 for i in (1, 2, 3, 4))
+
+
+@pytest.mark.parametrize("case", [0, 1, 2, 3, "3r", 4, 5, 6])
+def test_slice_groups(engine, case):
+    """FMO, every slice group map type: the kernel builds the map behind the
+    slice header, walks the addresses of the slice's group and takes
+    neighbour availability from them; full records vs oracle and vs the
+    generator's own expectation, and the map itself vs the generator's."""
+    from test_oracle_vs_generator import fmo_cfg, fmo_slices
+    cfg, cycle = fmo_cfg(case)
+    pairs = fmo_slices(cfg, cycle, 700)
+    slices = [s for s, _ in pairs]
+    run_case(engine, cfg, slices, TIER_T2)
+    run_case(engine, cfg, slices, TIER_T0)
+    # the map the kernel built for the last slice of the launch
+    from libh264_amd import capi
+    L = capi.engine_lib()
+    L.h264_amd_slice_group_map.argtypes = [C.c_void_p, C.c_uint32, C.c_void_p,
+                                           C.c_size_t]
+    n = cfg.width_mbs * cfg.height_mbs
+    got = np.zeros(n, dtype=np.uint8)
+    assert L.h264_amd_slice_group_map(engine.h, len(slices) - 1,
+                                      got.ctypes.data_as(C.c_void_p), n) == 0
+    assert np.array_equal(got, gen.slice_group_map(cfg, cycle))
+    assert L.h264_amd_slice_group_map(engine.h, len(slices),
+                                      got.ctypes.data_as(C.c_void_p),
+                                      n) == -34  # -ERANGE
+
+
+@pytest.mark.parametrize("field_pic", [0, 1, 2])
+def test_slice_groups_interlaced(engine, field_pic):
+    from test_oracle_vs_generator import fmo_cfg, fmo_slices
+    cfg, cycle = fmo_cfg(1, field_coding=1)
+    pairs = fmo_slices(cfg, cycle, 800, field_pic=field_pic)
+    run_case(engine, cfg, [s for s, _ in pairs], TIER_T2)
+
+
+def test_slice_groups_box_out_1080p(engine):
+    """box-out over a 1080p picture: 8160 map units walked on the LDS image,
+    two slices that together code the picture"""
+    from test_oracle_vs_generator import FMO_CASES  # noqa: F401
+    cfg = gen.cfg_1080p()
+    cfg.num_slice_groups_minus1 = 1
+    cfg.slice_group_map_type = 3
+    cfg.slice_group_change_direction_flag = 1
+    cfg.slice_group_change_rate_minus1 = 99
+    cycle = 37
+    slices = []
+    for k, (first, n, _a) in enumerate(gen.group_slices(cfg, cycle)):
+        slices.append(streams.rich_slice(cfg, 900 + k, 7, first, n,
+                                         slice_group_change_cycle=cycle,
+                                         density=2, hdr_extras=0))
+    assert sum(s.num_mbs for s in slices) == 8160
+    run_case(engine, cfg, slices, TIER_T0)

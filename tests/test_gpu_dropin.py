@@ -466,3 +466,22 @@ def test_single_nal_header_on_the_host_equals_device_path(monkeypatch, cabac):
         same_log(ref, got, stream=False)
     assert any(s < 0 for s in ref.statuses) or cabac
     assert sum(1 for e in ref.event_tuples() if e[0] == 4) >= 20
+
+
+@pytest.mark.parametrize("case", [0, 2, 3, 6])
+def test_reader_slice_groups(case):
+    """FMO through the drop-in reader: slice_data_mb callbacks carry the
+    addresses of the slice's group (h264_next_mb_addr,
+    ref src/h264_fmo.c:307-319), the host walks the map the kernel built."""
+    from test_oracle_vs_generator import fmo_cfg, fmo_slices
+    cfg, cycle = fmo_cfg(case)
+    nals = [gen.sps(cfg), gen.pps(cfg)]
+    want_addrs = []
+    for s, addrs in fmo_slices(cfg, cycle, 950):
+        nals.append(gen.slice_nal(cfg, s))
+        want_addrs += addrs.tolist()
+    data = streams.annexb(nals)
+    ref = orc.parse_stream(data, want=0)
+    got = prod.parse_stream(data)
+    same_log(ref, got, stream=True)
+    assert [e[1] for e in got.event_tuples() if e[0] == 7] == want_addrs
