@@ -417,6 +417,9 @@ struct gen {
 	uint32_t *addr_of;
 	int32_t *idx_of;
 	uint32_t n_addr;
+	/* MBAFF frame (field_coding 2, frame picture): macroblock pairs */
+	int mbaff;
+	uint8_t *ff; /* [num_mbs] mb_field_decoding_flag as finally inferred */
 };
 
 /* ---- slice groups (8.2.2), written from the standard ------------------------- */
@@ -571,11 +574,118 @@ static int16_t *coef_of(uint8_t *rec)
 	return (int16_t *)(rec + T2_HEAD);
 }
 
+/* ---- MBAFF (7.3.4, 7.4.4, 6.4.10, 6.4.12.2), written from the standard ------ */
+
+static uint32_t mb_address(const struct gen *g, uint32_t i)
+{
+	if (g->addr_of)
+		return g->addr_of[i];
+	return g->s->first_mb * (g->mbaff ? 2u : 1u) + i;
+}
+
+/* index in this slice of the TOP macroblock of pair `pair`, if the pair came
+ * before macroblock i (6.4.8: available = same slice, decoded earlier) */
+static int64_t pair_top_index(const struct gen *g, uint32_t i, int64_t pair)
+{
+	int64_t k;
+	if (pair < 0)
+		return -1;
+	if (g->addr_of) {
+		if ((uint64_t)(2 * pair) >= g->n_addr)
+			return -1;
+		k = g->idx_of[2 * pair];
+	} else {
+		k = 2 * (pair - (int64_t)g->s->first_mb);
+	}
+	/* an earlier pair of this slice */
+	return (k >= 0 && k < (int64_t)(i & ~1u)) ? k : -1;
+}
+
+/* 6.4.12.2, Table 6-4 for one neighbouring luma / chroma location of a
+ * macroblock in an MBAFF frame: which macroblock (index in this slice, -1
+ * not available) and which sample row yM of it holds (xN, yN), xN = -1 or
+ * yN = -1. */
+static int64_t mbaff_neighbour(const struct gen *g, uint32_t i, int left,
+			       int32_t yN, int32_t maxH, int32_t *yM)
+{
+	uint32_t addr = mb_address(g, i);
+	int64_t pair = addr / 2;
+	int top = (addr & 1u) == 0;
+	int cur_frame = !g->ff[i];
+	uint32_t col = (uint32_t)(pair % g->W);
+	if (left) {
+		int64_t a = col != 0 ? pair_top_index(g, i, pair - 1) : -1;
+		int a_frame;
+		if (a < 0)
+			return -1;
+		a_frame = !g->ff[a];
+		if (cur_frame) {
+			if (a_frame) {
+				*yM = yN;
+				return top ? a : a + 1;
+			}
+			/* frame macroblock beside a field pair: rows alternate
+			 * between the two field macroblocks */
+			*yM = top ? yN >> 1 : (yN + maxH) >> 1;
+			return (yN & 1) ? a + 1 : a;
+		}
+		if (a_frame) {
+			/* field macroblock beside a frame pair */
+			int32_t y2 = (yN << 1) + (top ? 0 : 1);
+			if (yN < maxH / 2) {
+				*yM = y2;
+				return a;
+			}
+			*yM = y2 - maxH;
+			return a + 1;
+		}
+		*yM = yN;
+		return top ? a : a + 1;
+	} else {
+		int64_t b;
+		if (cur_frame && !top) {
+			*yM = -1; /* the pair's own top macroblock */
+			return (int64_t)i - 1;
+		}
+		b = pair_top_index(g, i, pair - (int64_t)g->W);
+		if (b < 0)
+			return -1;
+		if (cur_frame) {
+			*yM = -1;
+			return b + 1;
+		}
+		if (top) {
+			if (!g->ff[b]) {
+				*yM = -2; /* 2 * yN */
+				return b + 1;
+			}
+			*yM = -1;
+			return b;
+		}
+		*yM = -1;
+		return b + 1;
+	}
+}
+
+static uint32_t ref_range(const struct gen *g, uint32_t i, uint32_t nref)
+{
+	/* field macroblocks of an MBAFF frame address fields: twice the range
+	 * (7.4.5.1); kept in 8 bits like the reference keeps it */
+	if (g->mbaff && g->ff[i])
+		return (2u * nref + 1u) & 0xffu;
+	return nref;
+}
+
+static int ref_present(const struct gen *g, uint32_t i, uint32_t nref)
+{
+	return nref > 0 || (g->mbaff && g->ff[i]);
+}
+
 /* availability + TotalCoeff of the neighbouring 4x4 block (6.4.11.4) */
 static uint32_t neighbour_nc(struct gen *g, uint32_t i, uint32_t comp,
 			     uint32_t blk, int chroma)
 {
-	uint32_t addr = g->addr_of ? g->addr_of[i] : g->s->first_mb + i;
+	uint32_t addr = mb_address(g, i);
 	int availA, availB;
 	int64_t ia = (int64_t)i - 1, ib = (int64_t)i - (int64_t)g->W;
 	uint32_t nA = 0, nB = 0, x, y, bw4, bh4;
@@ -595,6 +705,49 @@ static uint32_t neighbour_nc(struct gen *g, uint32_t i, uint32_t comp,
 					   {2, 3, 6, 7},
 					   {8, 9, 12, 13},
 					   {10, 11, 14, 15}};
+	if (g->mbaff) {
+		/* pairs: the neighbouring block may sit in either macroblock of
+		 * the neighbouring pair and in another row (6.4.12.2) */
+		int32_t maxH, yM = 0;
+		int64_t n;
+		if (chroma) {
+			x = blk & 1;
+			y = blk >> 1;
+			bw4 = 2;
+			maxH = g->cat == 1 ? 8 : 16;
+		} else {
+			x = lx[blk];
+			y = ly[blk];
+			bw4 = 4;
+			maxH = 16;
+		}
+		availA = availB = 1;
+		if (x > 0) {
+			nA = chroma ? cur[2 * y + x - 1] : cur[lidx[y][x - 1]];
+		} else {
+			n = mbaff_neighbour(g, i, 1, (int32_t)(4 * y), maxH, &yM);
+			availA = n >= 0;
+			if (availA) {
+				const uint8_t *l = g->nz + (size_t)n * 48 + comp * 16;
+				uint32_t r = (uint32_t)(yM < 0 ? yM + maxH : yM) / 4;
+				nA = chroma ? l[2 * r + bw4 - 1] : l[lidx[r][bw4 - 1]];
+			}
+		}
+		if (y > 0) {
+			nB = chroma ? cur[2 * (y - 1) + x] : cur[lidx[y - 1][x]];
+		} else {
+			n = mbaff_neighbour(g, i, 0, -1, maxH, &yM);
+			availB = n >= 0;
+			if (availB) {
+				const uint8_t *t = g->nz + (size_t)n * 48 + comp * 16;
+				uint32_t r = (uint32_t)(yM + maxH) / 4;
+				nB = chroma ? t[2 * r + x] : t[lidx[r][x]];
+			}
+		}
+		if (availA && availB)
+			return (nA + nB + 1) >> 1;
+		return availA ? nA : availB ? nB : 0;
+	}
 	if (chroma) {
 		x = blk & 1;
 		y = blk >> 1;
@@ -1026,20 +1179,22 @@ static void put_inter_mb(struct gen *g, uint32_t i, uint8_t *rec)
 			if (rec)
 				rec[8 + p] = (uint8_t)sub[p];
 		}
-		if (g->nref0 > 0 && mbt != MB_P_8x8ref0) {
+		if (ref_present(g, i, g->nref0) && mbt != MB_P_8x8ref0) {
 			for (p = 0; p < 4; p++)
 				if (pm[p] != PM_DIRECT && pm[p] != PM_L1) {
-					uint32_t v = rng_below(&g->r, g->nref0 + 1);
-					bw_te(w, v, g->nref0);
+					uint32_t v = rng_below(
+						&g->r, ref_range(g, i, g->nref0) + 1);
+					bw_te(w, v, ref_range(g, i, g->nref0));
 					if (rec)
 						rec[64 + p] = (uint8_t)v;
 				}
 		}
-		if (g->nref1 > 0) {
+		if (ref_present(g, i, g->nref1)) {
 			for (p = 0; p < 4; p++)
 				if (pm[p] != PM_DIRECT && pm[p] != PM_L0) {
-					uint32_t v = rng_below(&g->r, g->nref1 + 1);
-					bw_te(w, v, g->nref1);
+					uint32_t v = rng_below(
+						&g->r, ref_range(g, i, g->nref1) + 1);
+					bw_te(w, v, ref_range(g, i, g->nref1));
 					if (rec)
 						rec[68 + p] = (uint8_t)v;
 				}
@@ -1053,19 +1208,21 @@ static void put_inter_mb(struct gen *g, uint32_t i, uint8_t *rec)
 				for (s = 0; s < nsub[p]; s++)
 					put_mvd(g, mv1 ? mv1 + 8 * p + 2 * s : NULL);
 	} else if (pm[0] != PM_DIRECT) {
-		if (g->nref0 > 0)
+		if (ref_present(g, i, g->nref0))
 			for (p = 0; p < nparts; p++)
 				if (pm[p] != PM_L1) {
-					uint32_t v = rng_below(&g->r, g->nref0 + 1);
-					bw_te(w, v, g->nref0);
+					uint32_t v = rng_below(
+						&g->r, ref_range(g, i, g->nref0) + 1);
+					bw_te(w, v, ref_range(g, i, g->nref0));
 					if (rec)
 						rec[64 + p] = (uint8_t)v;
 				}
-		if (g->nref1 > 0)
+		if (ref_present(g, i, g->nref1))
 			for (p = 0; p < nparts; p++)
 				if (pm[p] != PM_L0) {
-					uint32_t v = rng_below(&g->r, g->nref1 + 1);
-					bw_te(w, v, g->nref1);
+					uint32_t v = rng_below(
+						&g->r, ref_range(g, i, g->nref1) + 1);
+					bw_te(w, v, ref_range(g, i, g->nref1));
 					if (rec)
 						rec[68 + p] = (uint8_t)v;
 				}
@@ -1255,6 +1412,7 @@ int h264gen_slice_nal(const struct h264gen_cfg *cfg,
 {
 	struct gen g;
 	uint32_t i, run = 0;
+	int skipped_prev = 0;
 	pthread_once(&s_once, tables_init);
 	if (cfg->width_mbs == 0 || sl->num_mbs == 0)
 		return -EINVAL;
@@ -1292,9 +1450,16 @@ int h264gen_slice_nal(const struct h264gen_cfg *cfg,
 		return finish(&g.w);
 	}
 
+	g.mbaff = cfg->field_coding == 2 && !sl->field_pic;
+	if (g.mbaff && (sl->num_mbs & 1u))
+		return -EINVAL; /* whole macroblock pairs */
 	g.nz = calloc((size_t)sl->num_mbs, 48);
-	if (g.nz == NULL)
+	g.ff = calloc((size_t)sl->num_mbs, 1);
+	if (g.nz == NULL || g.ff == NULL) {
+		free(g.nz);
+		free(g.ff);
 		return -ENOMEM;
+	}
 	if (cfg->num_slice_groups_minus1 > 0) {
 		/* the slice codes macroblocks of first_mb's group, in address
 		 * order (8.2.2: nextMbAddress) */
@@ -1310,17 +1475,21 @@ int h264gen_slice_nal(const struct h264gen_cfg *cfg,
 				   cfg, sl->slice_group_change_cycle,
 				   sl->field_pic, map, total)
 			 : -ENOMEM;
-		if (nm < 0 || !g.addr_of || !g.idx_of || sl->first_mb >= total) {
+		if (nm < 0 || !g.addr_of || !g.idx_of ||
+		    sl->first_mb * (g.mbaff ? 2u : 1u) >= total) {
 			free(map);
 			free(g.addr_of);
 			free(g.idx_of);
 			free(g.nz);
+			free(g.ff);
 			return nm < 0 ? (int)nm : -EINVAL;
 		}
 		for (a = 0; a < total; a++)
 			g.idx_of[a] = -1;
-		for (a = sl->first_mb; a < total && k < sl->num_mbs; a++)
-			if (map[a] == map[sl->first_mb]) {
+		/* first_mb_in_slice counts pairs in an MBAFF frame */
+		for (a = sl->first_mb * (g.mbaff ? 2u : 1u);
+		     a < total && k < sl->num_mbs; a++)
+			if (map[a] == map[sl->first_mb * (g.mbaff ? 2u : 1u)]) {
 				g.idx_of[a] = (int32_t)k;
 				g.addr_of[k++] = a;
 			}
@@ -1329,6 +1498,7 @@ int h264gen_slice_nal(const struct h264gen_cfg *cfg,
 			free(g.addr_of);
 			free(g.idx_of);
 			free(g.nz);
+			free(g.ff);
 			return -ERANGE;
 		}
 		g.n_addr = total;
@@ -1337,7 +1507,18 @@ int h264gen_slice_nal(const struct h264gen_cfg *cfg,
 		memset(t2, 0, (size_t)sl->num_mbs * t2_stride);
 	for (i = 0; i < sl->num_mbs; i++) {
 		uint8_t *rec = rec_of(&g, i);
+		const int top = !(i & 1u);
 		if (g.st == 2) {
+			if (g.mbaff) {
+				/* mb_field_decoding_flag with the top macroblock
+				 * of every pair (7.3.4) */
+				if (top) {
+					g.ff[i] = g.ff[i + 1] =
+						(uint8_t)rng_below(&g.r, 2);
+					bw_u(&g.w, g.ff[i], 1);
+				}
+				t_field_flag = g.ff[i] ? 0x04u : 0u;
+			}
 			put_intra_mb(&g, i, g.si ? 1 : 0, rec);
 			if (rec)
 				memcpy(rec + 16, g.nz + (size_t)i * 48, 48);
@@ -1351,6 +1532,31 @@ int h264gen_slice_nal(const struct h264gen_cfg *cfg,
 				skip = sl->end_with_skip ? 1 : 0;
 			if (skip) {
 				run++;
+				if (g.mbaff) {
+					if (top) {
+						/* decided with the bottom macroblock;
+						 * until then it counts as frame */
+						g.ff[i] = 0;
+					} else if (!skipped_prev) {
+						g.ff[i] = g.ff[i - 1];
+					} else {
+						/* both skipped: inferred from the
+						 * pair to the left, else the one
+						 * above, else frame (7.4.4) */
+						uint32_t addr = mb_address(&g, i);
+						int64_t pair = addr / 2, n = -1;
+						if (pair % g.W != 0)
+							n = pair_top_index(&g, i, pair - 1);
+						if (n < 0)
+							n = pair_top_index(
+								&g, i,
+								pair - (int64_t)g.W);
+						g.ff[i] = g.ff[i - 1] =
+							n >= 0 ? g.ff[n] : 0;
+					}
+					t_field_flag = g.ff[i] ? 0x04u : 0u;
+				}
+				skipped_prev = 1;
 				rec_head(rec, g.st == 1 ? MB_B_SKIP : MB_P_SKIP,
 					 0, MBF_SKIPPED, 0, 0);
 				if (last)
@@ -1358,7 +1564,23 @@ int h264gen_slice_nal(const struct h264gen_cfg *cfg,
 				continue;
 			}
 			bw_ue(&g.w, run);
+			if (g.mbaff) {
+				if (top) {
+					g.ff[i] = (uint8_t)rng_below(&g.r, 2);
+					bw_u(&g.w, g.ff[i], 1);
+				} else if (skipped_prev) {
+					/* the top macroblock was skipped: the flag
+					 * comes with this one and counts for both */
+					g.ff[i] = g.ff[i - 1] =
+						(uint8_t)rng_below(&g.r, 2);
+					bw_u(&g.w, g.ff[i], 1);
+				} else {
+					g.ff[i] = g.ff[i - 1];
+				}
+				t_field_flag = g.ff[i] ? 0x04u : 0u;
+			}
 			run = 0;
+			skipped_prev = 0;
 			if (rng_pm(&g.r, sl->pm_intra_in_inter))
 				put_intra_mb(&g, i, g.st == 1 ? 23 : 5, rec);
 			else
@@ -1369,6 +1591,7 @@ int h264gen_slice_nal(const struct h264gen_cfg *cfg,
 	}
 	bw_trailing(&g.w);
 	free(g.nz);
+	free(g.ff);
 	free(g.addr_of);
 	free(g.idx_of);
 	return finish(&g.w);

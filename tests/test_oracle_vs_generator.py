@@ -205,3 +205,68 @@ def test_slice_groups_interlaced(field_pic):
     assert [e[1] for e in mb_events] == want.tolist()
     n = cfg.width_mbs * cfg.height_mbs * (1 if field_pic else 2)
     assert sorted(want.tolist()) == list(range(n))
+
+
+def mbaff_slices(cfg, seed0, n=9, **kw):
+    """slices of MBAFF frames: whole pictures and pieces, first_mb_in_slice in
+    macroblock PAIRS"""
+    pairs = cfg.width_mbs * cfg.height_mbs
+    out = []
+    for k in range(n):
+        first = 0 if k % 3 == 0 else (k * 5) % (pairs - 2)
+        npairs = pairs - first if k % 2 == 0 else 1 + (k * 7) % (pairs - first)
+        out.append(streams.rich_slice(cfg, seed0 + k, (2, 0, 1)[k % 3], first,
+                                      2 * npairs, field_pic=0, **kw))
+    return out
+
+
+@pytest.mark.parametrize("cf", [1, 2, 3, 0])
+def test_mbaff_frames(cf):
+    """MBAFF: macroblock pairs, mb_field_decoding_flag with the top macroblock
+    (or with the bottom one behind a skipped top), inferred for skipped pairs,
+    neighbouring blocks per 6.4.12.2 (the generator from the standard's Table
+    6-4, the oracle after src/h264_macroblock.c:110-231), doubled ref_idx range
+    in field macroblocks.  Every record, field flags included."""
+    cfg = streams.small_cfg(cf=cf, field_coding=2)
+    slices = mbaff_slices(cfg, 1100)
+    rec = roundtrip(cfg, slices)
+    flags = np.concatenate([rec.mb_records(i)[:, 2] & 4
+                            for i in range(len(slices))])
+    assert 0 < flags.sum() < 4 * len(flags)  # both kinds of macroblock
+    assert all(h.field_pic_flag == 0 for h in rec.headers)
+    # addresses of the callbacks: 2 * first_mb_in_slice onwards
+    ev = [e for e in rec.event_tuples() if e[0] in (5, 7)]
+    k = 0
+    for s in slices:
+        assert ev[k][0] == 5
+        addrs = [e[1] for e in ev[k + 1:k + 1 + s.num_mbs]]
+        assert addrs == list(range(2 * s.first_mb, 2 * s.first_mb + s.num_mbs))
+        k += 1 + s.num_mbs
+
+
+def test_mbaff_skip_heavy_and_mixed_with_field_pictures():
+    cfg = streams.small_cfg(field_coding=2,
+                            bottom_field_pic_order_in_frame_present_flag=1)
+    slices = mbaff_slices(cfg, 1200, n=12, pm_skip=600, end_with_skip=1)
+    slices += mbaff_slices(cfg, 1300, n=6, pm_skip=850)
+    # field pictures of the same sequence are not MBAFF
+    slices += [streams.rich_slice(cfg, 1400 + k, (2, 0, 1)[k % 3],
+                                  field_pic=1 + k % 2) for k in range(4)]
+    roundtrip(cfg, slices)
+
+
+def test_mbaff_with_slice_groups():
+    """map units are macroblock pairs in an MBAFF frame (8.2.2.8)"""
+    cfg, cycle = fmo_cfg(1, field_coding=2)
+    m = gen.slice_group_map(cfg, cycle, 0)
+    assert len(m) == 2 * cfg.width_mbs * cfg.height_mbs
+    slices, want = [], []
+    for g in sorted(set(m.tolist())):
+        addrs = np.nonzero(m == g)[0]
+        assert len(addrs) % 2 == 0 and addrs[0] % 2 == 0
+        s = streams.rich_slice(cfg, 1500 + g, (2, 0, 1)[g % 3],
+                               int(addrs[0]) // 2, len(addrs), field_pic=0)
+        slices.append(s)
+        want += addrs.tolist()
+    rec = roundtrip(cfg, slices)
+    assert [e[1] for e in rec.event_tuples() if e[0] == 7] == want
