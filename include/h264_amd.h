@@ -414,6 +414,15 @@ H264_API int h264_amd_last_kernel_ms(struct h264_amd_engine *eng,
  * that launch built no map for it. */
 H264_API int h264_amd_slice_group_map(struct h264_amd_engine *e, uint32_t index,
 				      uint8_t *dst, size_t size);
+/* The maps of `count` slices of the last launch from position `first` on,
+ * `size` bytes of each into rows of `dst_pitch` bytes, in one copy; and the
+ * room the last launch gave each map (0: it built none).  The maps live until
+ * the engine's next decode launch: a caller that hands control to code that may
+ * launch again (the drop-in reader's callbacks) fetches them first. */
+H264_API int h264_amd_slice_group_maps(struct h264_amd_engine *e, uint32_t first,
+				       uint32_t count, uint8_t *dst,
+				       size_t dst_pitch, size_t size);
+H264_API size_t h264_amd_slice_group_map_pitch(const struct h264_amd_engine *e);
 
 /* ---- calibration and identification ---------------------------------------- */
 

@@ -81,6 +81,7 @@ struct h264_amd_params {
 	std::vector<dev_epoch> epochs;
 	uint64_t serial; /* bumped on every change */
 	uint32_t max_width_mbs, max_pic_mbs;
+	bool any_mbaff; /* an SPS with mb_adaptive_frame_field_flag was seen */
 };
 
 struct h264_amd_engine {
@@ -426,6 +427,7 @@ extern "C" int h264_amd_params_reset(struct h264_amd_params *p)
 	p->serial = next_serial();
 	p->max_width_mbs = 1;
 	p->max_pic_mbs = 1;
+	p->any_mbaff = false;
 	return 0;
 }
 
@@ -471,6 +473,8 @@ extern "C" int h264_amd_params_put_sps(struct h264_amd_params *p,
 	p->serial = next_serial();
 	if (d.pic_width_in_mbs > p->max_width_mbs)
 		p->max_width_mbs = d.pic_width_in_mbs;
+	if (d.mb_adaptive_frame_field_flag && !d.frame_mbs_only_flag)
+		p->any_mbaff = true;
 	uint64_t mbs = (uint64_t)d.pic_width_in_mbs * d.pic_height_in_map_units *
 		       (2 - (sps->frame_mbs_only_flag ? 1 : 0));
 	if (mbs > p->max_pic_mbs && mbs < 0x7fffffffu)
@@ -591,6 +595,32 @@ extern "C" int h264_amd_slice_group_map(struct h264_amd_engine *e, uint32_t inde
 	return 0;
 }
 
+/* the same for `count` slices from `first` on, `size` bytes of each into rows
+ * of `dst_pitch` bytes: one copy */
+extern "C" int h264_amd_slice_group_maps(struct h264_amd_engine *e, uint32_t first,
+					 uint32_t count, uint8_t *dst,
+					 size_t dst_pitch, size_t size)
+{
+	if (e == NULL || dst == NULL || dst_pitch < size)
+		return -EINVAL;
+	if (first > e->fmo_n || count > e->fmo_n - first || size > e->fmo_stride)
+		return -ERANGE;
+	if (count == 0 || size == 0)
+		return 0;
+	HIP_TRY(hipSetDevice(e->device));
+	HIP_TRY(hipMemcpy2DAsync(dst, dst_pitch,
+				 e->d_fmo_map + (size_t)first * e->fmo_stride,
+				 e->fmo_stride, size, count, hipMemcpyDeviceToHost,
+				 e->stream));
+	HIP_TRY(hipStreamSynchronize(e->stream));
+	return 0;
+}
+
+extern "C" size_t h264_amd_slice_group_map_pitch(const struct h264_amd_engine *e)
+{
+	return e != NULL && e->fmo_n > 0 ? e->fmo_stride : 0;
+}
+
 /* ---- slice decode ------------------------------------------------------------ */
 
 extern "C" int h264_amd_decode_slices(struct h264_amd_engine *e,
@@ -690,8 +720,10 @@ extern "C" int h264_amd_decode_slices(struct h264_amd_engine *e,
 	e->fmo_stride = a.fmo_stride;
 	e->fmo_n = a.fmo_map ? a.n : 0;
 
+	a.row_mbaff = params->any_mbaff ? 1u : 0u;
 	{
-		uint32_t tail = SD_REC_BYTES + 16u * a.row_pitch;
+		uint32_t tail = SD_REC_BYTES +
+				(a.row_mbaff ? SD_ROW_STRIDE_MBAFF : 16u) * a.row_pitch;
 		if (tail < SD_STAGE_BYTES)
 			tail = SD_STAGE_BYTES;
 		a.wave_lds_bytes = (SD_STAGE_OFF + tail + 255u) & ~255u;
@@ -699,31 +731,26 @@ extern "C" int h264_amd_decode_slices(struct h264_amd_engine *e,
 	size_t lds = SD_TABS_BYTES + (size_t)SD_WAVES_PER_BLOCK * a.wave_lds_bytes;
 	if (lds > 160u * 1024u)
 		return -E2BIG;
-	if (lds > 48u * 1024u)
-		HIP_TRY(hipFuncSetAttribute(
-			(const void *)h264_amd_k_decode_slices,
-			hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
 	/* more than one round of 16 waves per CU: the 5-waves-per-SIMD build
-	 * (H264_AMD_DECODE_W5=0/1 forces one or the other) */
+	 * (H264_AMD_DECODE_W5=0/1 forces one or the other); a parameter set
+	 * that allows MBAFF: the pair-aware build */
 	bool w5 = a.n > 4096u;
 	{
 		const char *v = getenv("H264_AMD_DECODE_W5");
 		if (v != NULL && (v[0] == '0' || v[0] == '1'))
 			w5 = v[0] == '1';
 	}
-	if (w5 && lds > 48u * 1024u)
+	void (*kern)(sd_args) = params->any_mbaff ? h264_amd_k_decode_slices_mbaff :
+				w5 ? h264_amd_k_decode_slices_w5 :
+				     h264_amd_k_decode_slices;
+	if (lds > 48u * 1024u)
 		HIP_TRY(hipFuncSetAttribute(
-			(const void *)h264_amd_k_decode_slices_w5,
+			(const void *)kern,
 			hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
 	HIP_TRY(hipEventRecord(e->ev[FAM_DECODE][0], e->stream));
-	if (w5)
-		hipLaunchKernelGGL(h264_amd_k_decode_slices_w5,
-				   dim3((a.n + SD_WAVES_PER_BLOCK - 1) / SD_WAVES_PER_BLOCK),
-				   dim3(64 * SD_WAVES_PER_BLOCK), lds, e->stream, a);
-	else
-		hipLaunchKernelGGL(h264_amd_k_decode_slices,
-				   dim3((a.n + SD_WAVES_PER_BLOCK - 1) / SD_WAVES_PER_BLOCK),
-				   dim3(64 * SD_WAVES_PER_BLOCK), lds, e->stream, a);
+	hipLaunchKernelGGL(kern,
+			   dim3((a.n + SD_WAVES_PER_BLOCK - 1) / SD_WAVES_PER_BLOCK),
+			   dim3(64 * SD_WAVES_PER_BLOCK), lds, e->stream, a);
 	HIP_TRY(hipGetLastError());
 	HIP_TRY(hipEventRecord(e->ev[FAM_DECODE][1], e->stream));
 	e->timed[FAM_DECODE] = true;

@@ -1054,7 +1054,7 @@ static void dump_mvd(struct h264_dump *d, const uint8_t *rec, uint32_t list,
 }
 
 static void dump_macroblock(struct h264_dump *d, const struct h264_ctx *ctx,
-			    const uint8_t *rec, uint32_t mb_addr)
+			    const uint8_t *rec, uint32_t mb_addr, int field_flag)
 {
 	const struct h264_amd_mb_summary *s =
 		(const struct h264_amd_mb_summary *)rec;
@@ -1067,7 +1067,11 @@ static void dump_macroblock(struct h264_dump *d, const struct h264_ctx *ctx,
 
 	begin_item(d);
 	FV("mbAddr", mb_addr);
-	FV("MbaffFrameFlag", 0);
+	FV("MbaffFrameFlag", ctx->derived.MbaffFrameFlag);
+	/* read with the top macroblock of a pair, or with the bottom one behind
+	 * a skipped top (ref src/h264_syntax_slice_data.h:755-761) */
+	if (field_flag >= 0)
+		FV("mb_field_decoding_flag", field_flag);
 	FV("mb_addr", (uint64_t)sh->frame_num * 10000u + mb_addr);
 	FV("mb_type", s->raw_mb_type);
 
@@ -1214,10 +1218,11 @@ static int dump_slice_data(struct h264_dump *d, struct h264_ctx *ctx)
 	struct h264_bitstream bs;
 	void *d_nal = NULL, *d_desc = NULL, *d_res = NULL, *d_hdr = NULL,
 	     *d_mb = NULL;
-	uint8_t *recs = NULL;
+	uint8_t *recs = NULL, *group_map = NULL;
 	size_t cap[5] = {0, 0, 0, 0, 0};
-	uint32_t epoch = 0, stride, mbcap, m, run = 0;
-	int res;
+	uint32_t epoch = 0, stride, mbcap, m, run = 0, cur;
+	const uint32_t pic_mbs = ctx->derived.PicSizeInMbs;
+	int res, had_run = 0;
 
 	if (ctx->pps == NULL || ctx->pps->entropy_coding_mode_flag)
 		return 0; /* CABAC not supported for parsing (ref :715-717) */
@@ -1287,6 +1292,13 @@ static int dump_slice_data(struct h264_dump *d, struct h264_ctx *ctx)
 				   : h264_amd_download(eng, recs, d_mb,
 						       (size_t)r.mb_count * stride);
 	}
+	if (res == 0 && ctx->pps->num_slice_groups_minus1 > 0) {
+		/* the map the kernel walked (ref src/h264_fmo.c:307-319) */
+		group_map = malloc(pic_mbs ? pic_mbs : 1);
+		res = group_map == NULL
+			      ? -ENOMEM
+			      : h264_amd_slice_group_map(eng, 0, group_map, pic_mbs);
+	}
 	h264_amd_free(eng, d_nal);
 	h264_amd_free(eng, d_desc);
 	h264_amd_free(eng, d_res);
@@ -1296,9 +1308,11 @@ static int dump_slice_data(struct h264_dump *d, struct h264_ctx *ctx)
 	h264_bs_clear(&bs);
 	if (res < 0) {
 		free(recs);
+		free(group_map);
 		return res;
 	}
 
+	cur = r.first_mb_in_slice * (1u + (uint32_t)ctx->derived.MbaffFrameFlag);
 	begin_struct(d);
 	begin_array(d);
 	/* skipped macroblocks show as their run, coded ones in full; the
@@ -1313,6 +1327,16 @@ static int dump_slice_data(struct h264_dump *d, struct h264_ctx *ctx)
 					  H264_SLICE_TYPE_I &&
 				  ctx->slice.hdr.slice_type % 5u !=
 					  H264_SLICE_TYPE_SI;
+		uint32_t addr = cur;
+		int field_flag = -1;
+		if (group_map != NULL && cur < pic_mbs) {
+			uint32_t i = cur + 1;
+			while (i < pic_mbs && group_map[i] != group_map[cur])
+				i++;
+			cur = i;
+		} else {
+			cur++;
+		}
 		if (skipped) {
 			run++;
 			continue;
@@ -1320,18 +1344,24 @@ static int dump_slice_data(struct h264_dump *d, struct h264_ctx *ctx)
 		/* a run is coded in front of every coded macroblock of a P / B
 		 * slice (0 when none is skipped), and a last one may end the
 		 * slice */
+		had_run = run > 0;
 		if (inter_slice && (rec != NULL || run > 0)) {
 			begin_item(d);
 			FV("mb_skip_run", run);
 			end_item(d);
 			run = 0;
 		}
+		if (rec != NULL && ctx->derived.MbaffFrameFlag &&
+		    (addr % 2 == 0 || (inter_slice && had_run)))
+			field_flag = (((const struct h264_amd_mb_summary *)rec)->flags &
+				      H264_AMD_MB_FIELD) != 0;
 		if (rec != NULL)
-			dump_macroblock(d, ctx, rec, r.first_mb_in_slice + m);
+			dump_macroblock(d, ctx, rec, addr, field_flag);
 	}
 	end_array(d, "mb");
 	end_struct(d, "slice_data");
 	free(recs);
+	free(group_map);
 	return r.status < 0 ? r.status : 0;
 }
 

@@ -87,6 +87,10 @@ struct h264_reader {
 	uint32_t *h_mb;
 	uint32_t *h_big; /* one slice that outgrew the batch's mb_capacity */
 	size_t hcap_results, hcap_headers, hcap_mb, hcap_big;
+	/* slice group maps of the batch and of that one slice, fmo_pitch bytes
+	 * each (0: the launch built none) */
+	uint8_t *h_fmo, *h_fmo_big;
+	size_t hcap_fmo, hcap_fmo_big, fmo_pitch;
 };
 
 /* direction-agnostic syntax cursor with an error latch (paramsets.c) */

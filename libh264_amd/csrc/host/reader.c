@@ -83,6 +83,8 @@ int h264_reader_destroy(struct h264_reader *rd)
 	free(rd->h_headers);
 	free(rd->h_mb);
 	free(rd->h_big);
+	free(rd->h_fmo);
+	free(rd->h_fmo_big);
 	h264_ctx_destroy(rd->ctx);
 	free(rd);
 	return 0;
@@ -285,6 +287,24 @@ static int batch_setup(struct h264_reader *rd, struct rd_batch *b,
 	return res;
 }
 
+/* The slice group maps of the launch just made, to the host: the engine keeps
+ * them only until its next launch, and a callback may well cause one (a dump
+ * of the slice does). */
+static int fetch_maps(struct h264_reader *rd, struct h264_amd_engine *eng,
+		      size_t count, uint8_t **h_maps, size_t *hcap)
+{
+	size_t pitch = h264_amd_slice_group_map_pitch(eng);
+	int res;
+	rd->fmo_pitch = pitch;
+	if (pitch == 0)
+		return 0;
+	res = host_grow((void **)h_maps, hcap, count * pitch);
+	if (res < 0)
+		return res;
+	return h264_amd_slice_group_maps(eng, 0, (uint32_t)count, *h_maps, pitch,
+					 pitch);
+}
+
 /* make slice `idx` available in the host images */
 static int batch_fetch(struct h264_reader *rd, struct rd_batch *b, size_t idx)
 {
@@ -335,6 +355,8 @@ static int batch_fetch(struct h264_reader *rd, struct rd_batch *b, size_t idx)
 					cn * sizeof(*rd->h_headers));
 	if (res == 0 && mb_bytes)
 		res = h264_amd_download(b->eng, rd->h_mb, rd->d_mb, mb_bytes);
+	if (res == 0)
+		res = fetch_maps(rd, b->eng, cn, &rd->h_fmo, &rd->hcap_fmo);
 	if (res < 0)
 		return res;
 	b->lo = lo;
@@ -384,6 +406,11 @@ static int retry_big_slice(struct h264_reader *rd, struct rd_batch *b,
 		if (res < 0)
 			return res;
 	} while (r->status == H264_AMD_E_MB_OVERFLOW && cap < RD_MAX_MB_CAP);
+	/* this slice's map is the only one of that launch; the batch's are on
+	 * the host already */
+	res = fetch_maps(rd, b->eng, 1, &rd->h_fmo_big, &rd->hcap_fmo_big);
+	if (res < 0)
+		return res;
 	*t0 = NULL;
 	if (b->tier == H264_AMD_TIER_T0 && r->mb_count > 0) {
 		size_t bytes = (size_t)r->mb_count * 4;
@@ -402,31 +429,19 @@ static int retry_big_slice(struct h264_reader *rd, struct rd_batch *b,
 
 /* Addresses of a slice's macroblocks under slice groups: the reference walks
  * its map with h264_next_mb_addr (src/h264_fmo.c:307-319); the map is the one
- * the kernel built for this slice (index `kidx` of the last launch). */
-static int slice_addresses(struct h264_reader *rd, uint32_t kidx,
+ * the kernel built for this slice, fetched behind the launch (fetch_maps). */
+static int slice_addresses(struct h264_reader *rd, const uint8_t *map,
 			   const struct h264_amd_slice_result *r, uint32_t **ret)
 {
 	struct h264_ctx *ctx = rd->ctx;
-	struct h264_amd_engine *eng;
-	uint32_t pic = ctx->derived.PicSizeInMbs, m, cur = r->first_mb_in_slice;
-	uint8_t *map;
+	uint32_t pic = ctx->derived.PicSizeInMbs, m;
+	uint32_t cur = r->first_mb_in_slice * (1u + (uint32_t)ctx->derived.MbaffFrameFlag);
 	uint32_t *addrs;
-	int res = h264_host_engine(&eng);
-	if (res < 0)
-		return res;
-	map = malloc(pic ? pic : 1);
+	if (map == NULL || pic > rd->fmo_pitch)
+		return -EPROTO;
 	addrs = malloc((r->mb_count ? r->mb_count : 1) * sizeof(*addrs));
-	if (map == NULL || addrs == NULL) {
-		free(map);
-		free(addrs);
+	if (addrs == NULL)
 		return -ENOMEM;
-	}
-	res = h264_amd_slice_group_map(eng, kidx, map, pic);
-	if (res < 0) {
-		free(map);
-		free(addrs);
-		return res;
-	}
 	for (m = 0; m < r->mb_count; m++) {
 		uint32_t i = cur + 1;
 		addrs[m] = cur;
@@ -437,7 +452,6 @@ static int slice_addresses(struct h264_reader *rd, uint32_t kidx,
 		}
 		cur = i;
 	}
-	free(map);
 	*ret = addrs;
 	return 0;
 }
@@ -445,7 +459,7 @@ static int slice_addresses(struct h264_reader *rd, uint32_t kidx,
 static int replay_slice(struct h264_reader *rd, const uint8_t *nal, size_t len,
 			const struct h264_amd_slice_result *r,
 			const struct h264_slice_header *sh, const uint32_t *t0,
-			uint32_t kidx)
+			const uint8_t *group_map)
 {
 	struct h264_ctx *ctx = rd->ctx;
 	const struct h264_ctx_cbs *cbs = &rd->cbs;
@@ -480,15 +494,18 @@ static int replay_slice(struct h264_reader *rd, const uint8_t *nal, size_t len,
 			cbs->slice_data_begin(ctx, &ctx->slice.hdr, rd->userdata);
 		if (cbs->slice_data_mb) {
 			uint32_t *addrs = NULL;
+			/* macroblock pairs are numbered 2n, 2n + 1
+			 * (ref src/h264_cavlc.c:725) */
+			uint32_t first = r->first_mb_in_slice *
+					 (1u + (uint32_t)ctx->derived.MbaffFrameFlag);
 			if (ctx->pps->num_slice_groups_minus1 > 0) {
-				int res = slice_addresses(rd, kidx, r, &addrs);
+				int res = slice_addresses(rd, group_map, r, &addrs);
 				if (res < 0)
 					return res;
 			}
 			for (m = 0; m < r->mb_count; m++)
 				cbs->slice_data_mb(ctx, &ctx->slice.hdr,
-						   addrs ? addrs[m]
-							 : r->first_mb_in_slice + m,
+						   addrs ? addrs[m] : first + m,
 						   t0[m] & 0xffu, rd->userdata);
 			free(addrs);
 		}
@@ -537,10 +554,11 @@ static int replay_nal(struct h264_reader *rd, struct rd_batch *b,
 		const struct h264_amd_slice_result *r;
 		struct h264_amd_slice_result big;
 		const uint32_t *t0;
+		const uint8_t *group_map;
 		size_t k;
 		if (hs != NULL) {
 			/* header parsed on the host (slicehdr.c) */
-			res = replay_slice(rd, nal, len, &hs->r, &hs->sh, NULL, 0);
+			res = replay_slice(rd, nal, len, &hs->r, &hs->sh, NULL, NULL);
 			if (res < 0)
 				return res;
 			if (cbs->slice)
@@ -556,19 +574,16 @@ static int replay_nal(struct h264_reader *rd, struct rd_batch *b,
 		r = &rd->h_results[k];
 		t0 = b->tier == H264_AMD_TIER_T0 ? rd->h_mb + k * b->mb_cap
 						 : NULL;
-		uint32_t kidx = (uint32_t)k;
+		group_map = rd->fmo_pitch ? rd->h_fmo + k * rd->fmo_pitch : NULL;
 		if (r->status == H264_AMD_E_MB_OVERFLOW) {
 			res = retry_big_slice(rd, b, (size_t)slice, &big, &t0);
 			if (res < 0)
 				return res;
 			r = &big;
-			kidx = 0; /* decoded again on its own */
-			/* that launch replaced the engine's per-slice scratch
-			 * (slice group maps): the chunk is fetched again for
-			 * the slices behind this one */
-			b->hi = b->lo;
+			group_map = rd->fmo_pitch ? rd->h_fmo_big : NULL;
 		}
-		res = replay_slice(rd, nal, len, r, &rd->h_headers[k], t0, kidx);
+		res = replay_slice(rd, nal, len, r, &rd->h_headers[k], t0,
+				   group_map);
 		if (res < 0)
 			return res;
 		if (cbs->slice)

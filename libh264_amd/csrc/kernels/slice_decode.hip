@@ -36,7 +36,8 @@
  *
  * Slice groups (FMO): the map of 8.2.2 is built per slice by sd_fmo_build and
  * walked by sd_fmo_next (ref src/h264_fmo.c).
- * Out of scope (status H264_AMD_E_UNSUPPORTED): MBAFF frames.
+ * MBAFF frames: macroblock pairs, see PairCtx (a third instantiation of the
+ * slice-data walk).
  */
 #include <hip/hip_runtime.h>
 #include <errno.h>
@@ -74,6 +75,7 @@ struct SliceState {
 	uint32_t cat, W, bdl, bdc, pcm_chroma;
 	uint32_t t8x8_mode, direct8x8, entropy, unsupported;
 	/* slice groups */
+	uint32_t mbaff; /* MbaffFrameFlag */
 	uint32_t fmo; /* num_slice_groups_minus1 (0: none) */
 	uint32_t fmo_type, pps_version, frame_mbs_only, map_units_h;
 	uint32_t change_cycle, change_rate;
@@ -476,7 +478,8 @@ sd_slice_header(WaveBits &wb, uint32_t lane, uint8_t *stage, SliceState &S,
 	S.frame_mbs_only = sps.frame_mbs_only_flag;
 	S.map_units_h = sps.pic_height_in_map_units;
 	S.change_rate = pps.slice_group_change_rate_minus1 + 1u;
-	S.unsupported = sps.mb_adaptive_frame_field_flag && !field_pic;
+	S.mbaff = (sps.mb_adaptive_frame_field_flag && !field_pic) ? 1u : 0u;
+	S.unsupported = 0;
 	return 0;
 }
 
@@ -622,8 +625,8 @@ __device__ __forceinline__ int sd_fmo_build(const dev_fmo *f, const SliceState &
 	for (uint32_t a0 = 0; a0 < pic_mbs; a0 += 64u) {
 		/* lanes past the end repeat the last macroblock's store */
 		uint32_t a = a0 + lane < pic_mbs ? a0 + lane : pic_mbs - 1u;
-		uint32_t unit = (S.frame_mbs_only || S.field_pic)
-					? a
+		uint32_t unit = (S.frame_mbs_only || S.field_pic) ? a
+				: S.mbaff		      ? a >> 1
 					: (a / (2u * W)) * W + (a % W);
 		uint32_t g3 = (bits[(unit >> 5) & (SD_STAGE_BYTES / 4u - 1u)] >>
 			       (unit & 31u)) & 1u ? 0u : 1u;
@@ -1227,11 +1230,146 @@ __device__ __forceinline__ void sd_next_mb(MbCtx &m, uint8_t *row, uint8_t *dump
 		mbx = 0;
 }
 
+/* ---- MBAFF frames: macroblock pairs ----------------------------------------
+ * (ref src/h264_macroblock.c:110-231 neighbouring locations 6.4.12.2,
+ * src/h264_slice_data.c:1145-1206 field flag inference and ref_idx range,
+ * src/h264_syntax_slice_data.h:754-761 where the flag is read.)
+ * The neighbour context of MbCtx stays what it is -- per lane nA + nB of the
+ * lane's block -- only where the external parts come from changes: the block
+ * to the LEFT of a left-edge block sits in one of the TWO macroblocks of the
+ * pair to the left, in a row that depends on frame / field coding of both
+ * pairs (Table 6-4); the block ABOVE a top-edge block sits in the bottom row
+ * of the pair above (either macroblock) or of this pair's own top macroblock.
+ * So the lanes keep the nz_coeff of both macroblocks of the left pair and of
+ * this pair's top macroblock, and a column of the row context holds the
+ * bottom rows of both macroblocks of the pair above (32 bytes per column:
+ * [0,12) top macroblock, [12,16) slice-group tag, [16,28) bottom macroblock,
+ * [28] the pair's field flag). */
+#define SD_ROW_STRIDE_MBAFF 32u
+
+struct PairCtx {
+	/* per lane, changing */
+	uint32_t left_top, left_bot; /* nz_coeff of the pair to the left */
+	uint32_t pair_top; /* nz_coeff of this pair's top macroblock */
+	/* per lane, constant */
+	uint32_t y4; /* sample row of the lane's block: 0, 4, 8, 12 */
+	uint32_t maxh; /* 16, or MbHeightC for chroma blocks */
+	uint32_t base; /* 16 * component */
+	uint32_t chroma; /* 1: 4:2:0 / 4:2:2 chroma block */
+	uint32_t own_src; /* lane of the block above in the pair's top MB */
+	/* uniform */
+	uint32_t left_field; /* field flag of the pair to the left */
+	uint32_t pair_field; /* of this pair, as far as known */
+	uint32_t top_skipped;
+};
+
+__device__ __forceinline__ void sd_pair_consts(PairCtx &P, uint32_t lane,
+					       uint32_t cat)
+{
+	const uint32_t comp = lane >> 4, b = lane & 15u;
+	const bool chroma = lane < 48 && comp > 0 && (cat == 1 || cat == 2);
+	const uint32_t lx = (b & 1u) | ((b >> 1) & 2u);
+	const uint32_t ly = ((b >> 1) & 1u) | ((b >> 2) & 2u);
+	const uint32_t cx = b & 1u, cy = b >> 1;
+	const uint32_t h4 = cat == 1 ? 2u : 4u;
+	P.chroma = chroma ? 1u : 0u;
+	P.base = 16u * comp;
+	P.y4 = 4u * (chroma ? cy : ly);
+	P.maxh = chroma ? 4u * h4 : 16u;
+	P.own_src = chroma ? 16u * comp + 2u * (h4 - 1u) + cx
+			   : 16u * comp + blk_at(lx, 3);
+	P.left_top = P.left_bot = P.pair_top = 0;
+	P.left_field = P.pair_field = P.top_skipped = 0;
+}
+
+/* a macroblock of a pair starts: external neighbour sums (see above).
+ * top: 1 for the pair's top macroblock; field: this macroblock's flag;
+ * availA / availB: the pair to the left / above is part of this slice;
+ * above_field: field flag of the pair above */
+__device__ __forceinline__ void sd_mb_begin_mbaff(MbCtx &m, const PairCtx &P,
+						  const uint8_t *row, uint32_t mbx,
+						  uint32_t top, uint32_t field,
+						  uint32_t above_field)
+{
+	const uint32_t cur_frame = field ^ 1u, a_frame = P.left_field ^ 1u;
+	/* ---- left (xN < 0): which macroblock of the left pair, which row ---- */
+	uint32_t yN = P.y4, src_bot, yM;
+	if (cur_frame) {
+		if (a_frame) {
+			src_bot = top ^ 1u;
+			yM = yN;
+		} else {
+			/* block rows start on even sample rows: always the top
+			 * field macroblock */
+			src_bot = 0;
+			yM = top ? yN >> 1 : (yN + P.maxh) >> 1;
+		}
+	} else {
+		if (a_frame) {
+			uint32_t lower = yN < (P.maxh >> 1) ? 0u : 1u; /* per lane */
+			src_bot = lower;
+			yM = (yN << 1) + (top ^ 1u) - (lower ? P.maxh : 0u);
+		} else {
+			src_bot = top ^ 1u;
+			yM = yN;
+		}
+	}
+	uint32_t r = yM >> 2;
+	uint32_t src = P.chroma ? P.base + 2u * r + 1u
+				: P.base + 5u + 2u * (r & 1u) + 8u * (r >> 1);
+	uint32_t lt = (uint32_t)__shfl((int)P.left_top, (int)(src & 63u));
+	uint32_t lb = (uint32_t)__shfl((int)P.left_bot, (int)(src & 63u));
+	uint32_t lv = src_bot ? lb : lt;
+	/* ---- above (yN < 0) ---- */
+	uint32_t own = cur_frame & (top ^ 1u); /* the pair's own top MB */
+	uint32_t use_top_mb = (cur_frame ^ 1u) & top & above_field;
+	uint32_t tv_row = row[SD_ROW_STRIDE_MBAFF * mbx + (use_top_mb ? 0u : 16u) +
+			      (uint32_t)(m.top_slot & 15)];
+	uint32_t tv_own = (uint32_t)__shfl((int)P.pair_top, (int)(P.own_src & 63u));
+	uint32_t tv = own ? tv_own : tv_row;
+	bool extA = m.a_ext != 0xffu && m.availA != 0;
+	bool extB = m.top_slot >= 0 && (own != 0 || m.availB != 0);
+	m.sum = (extA ? lv : 0u) + (extB ? tv : 0u);
+	bool hasA = m.a_int != 0xffu || extA;
+	bool hasB = m.b_int != 0xffu || extB;
+	m.bothv = (hasA && hasB) ? 1u : 0u;
+}
+
+/* a macroblock of a pair is done */
+__device__ __forceinline__ void sd_next_mb_mbaff(MbCtx &m, PairCtx &P, uint8_t *row,
+						 uint8_t *dump, uint32_t mbx,
+						 uint32_t top, uint32_t field,
+						 uint32_t lane)
+{
+	if (top) {
+		P.pair_top = m.cur;
+	} else {
+		/* the pair is complete: its bottom rows replace those of the
+		 * pair above in this column, and it becomes the left pair */
+		uint8_t *col = row + SD_ROW_STRIDE_MBAFF * mbx;
+		uint32_t slot = (uint32_t)(m.row_slot & 15);
+		*lds_sel(col + slot, dump, m.row_slot >= 0, lane) =
+			(uint8_t)P.pair_top;
+		*lds_sel(col + 16u + slot, dump, m.row_slot >= 0, lane) =
+			(uint8_t)m.cur;
+		col[28] = (uint8_t)field; /* every lane, same byte */
+		P.left_top = P.pair_top;
+		P.left_bot = m.cur;
+	}
+	/* (kept out of the branch above: assigned there, the optimiser takes
+	 * the value for lane-dependent and the whole cursor with it) */
+	P.left_field = top ? P.left_field : field;
+	m.left = m.cur;
+	m.cur = 0;
+}
+
 /* ---- slice data (ref src/h264_syntax_slice_data.h:701-787) -------------- */
 /* ONLY_I: instantiated for I slices (not SI) alone, so that everything the
  * P / B / SI syntax needs is compiled out of the intra loop instead of being
  * carried through it in registers. */
-template <bool ONLY_I>
+/* MBAFF: instantiated for the slices of MBAFF frames (never with ONLY_I):
+ * macroblock pairs, see PairCtx */
+template <bool ONLY_I, bool MBAFF>
 __device__ __forceinline__ int
 sd_slice_data(WaveBits &wb, const VlcTabs &vt, uint32_t cbp_map, uint32_t lane,
 	      uint8_t *stage, uint8_t *row, const SliceState &S, OutCtx &o,
@@ -1268,6 +1406,11 @@ sd_slice_data(WaveBits &wb, const VlcTabs &vt, uint32_t cbp_map, uint32_t lane,
 	sd_mb_consts(m, lane, cat);
 	uint32_t mbx = S.first_mb % W;
 	uint32_t mbidx = 0;
+	/* bytes of row context per macroblock column */
+	const uint32_t RS = MBAFF ? SD_ROW_STRIDE_MBAFF : 16u;
+	PairCtx P;
+	if (MBAFF)
+		sd_pair_consts(P, lane, cat);
 	/* Slice groups (generic instantiation only).  The slice walks the
 	 * addresses of ONE group in increasing order, so "macroblock X is part
 	 * of this slice and came before" (the reference's available flag,
@@ -1275,11 +1418,13 @@ sd_slice_data(WaveBits &wb, const VlcTabs &vt, uint32_t cbp_map, uint32_t lane,
 	 * left neighbour, and for the one above, the last address this slice
 	 * visited in that column (kept as a tag in the column's row context). */
 	const bool fmo = !ONLY_I && S.fmo != 0;
-	uint32_t cur_addr = S.first_mb, prev_addr = 0xffffffffu;
+	/* (first_mb_in_slice counts pairs in an MBAFF frame; with slice groups
+	 * the tags name the TOP macroblock of the last pair of a column) */
+	uint32_t cur_addr = S.first_mb * (MBAFF ? 2u : 1u), prev_addr = 0xffffffffu;
 	if (fmo) {
 		for (uint32_t c0 = 0; c0 < W; c0 += 64u) {
 			uint32_t c = c0 + lane < W ? c0 + lane : W - 1u;
-			*reinterpret_cast<uint32_t *>(row + 16u * c + 12u) =
+			*reinterpret_cast<uint32_t *>(row + RS * c + 12u) =
 				0xffffffffu;
 		}
 	}
@@ -1287,13 +1432,46 @@ sd_slice_data(WaveBits &wb, const VlcTabs &vt, uint32_t cbp_map, uint32_t lane,
 #define SD_FMO_STEP()                                                          \
 	do {                                                                   \
 		if (fmo) {                                                     \
-			uint32_t col_ = cur_addr % W;                          \
-			*reinterpret_cast<uint32_t *>(row + 16u * col_ + 12u) = \
-				cur_addr;                                      \
-			prev_addr = cur_addr;                                  \
+			if (!MBAFF || (cur_addr & 1u)) {                       \
+				uint32_t t_ = MBAFF ? cur_addr - 1u : cur_addr; \
+				uint32_t col_ = (MBAFF ? t_ >> 1 : t_) % W;    \
+				*reinterpret_cast<uint32_t *>(row + RS * col_ + \
+							      12u) = t_;       \
+				prev_addr = t_;                                \
+			}                                                      \
 			cur_addr = sd_fmo_next(fmo_map, pic_mbs, cur_addr, lane); \
-			mbx = cur_addr % W;                                    \
+			mbx = (MBAFF ? cur_addr >> 1 : cur_addr) % W;          \
+		} else if (MBAFF) {                                            \
+			cur_addr++;                                            \
+			if (!(cur_addr & 1u)) {                                \
+				mbx++;                                         \
+				if (mbx == W)                                  \
+					mbx = 0;                               \
+			}                                                      \
 		}                                                              \
+	} while (0)
+	/* MBAFF: is the pair to the left / above part of this slice (ref
+	 * src/h264_macroblock.c:327-350), and the field flag of the pair above */
+#define SD_PAIR_NEIGHBOURS()                                                   \
+	do {                                                                   \
+		uint32_t pair_ = cur_addr >> 1;                                \
+		uint32_t first_ = S.first_mb;                                  \
+		m.availA = (mbx != 0 && pair_ >= first_ + 1u &&                \
+			    (mbidx >> 1) >= 1u)                                \
+				   ? 1u                                        \
+				   : 0u;                                       \
+		m.availB = (pair_ >= first_ + W && (mbidx >> 1) >= W) ? 1u : 0u; \
+		if (fmo) {                                                     \
+			uint32_t tag_ = wb_uniform(                            \
+				*reinterpret_cast<const uint32_t *>(           \
+					row + RS * mbx + 12u));                \
+			uint32_t top_ = cur_addr & ~1u;                        \
+			m.availA = (mbx != 0 && prev_addr + 2u == top_) ? 1u : 0u; \
+			m.availB = (top_ >= 2u * W && tag_ == top_ - 2u * W)   \
+					   ? 1u                                \
+					   : 0u;                               \
+		}                                                              \
+		above_field = wb_uniform((uint32_t)row[RS * mbx + 28u]) & 1u;  \
 	} while (0)
 	/* field pictures: every macroblock carries the picture's flag
 	 * (ref src/h264_slice_data.c:1145-1149) */
@@ -1308,6 +1486,7 @@ sd_slice_data(WaveBits &wb, const VlcTabs &vt, uint32_t cbp_map, uint32_t lane,
 	asm volatile("" : "+v"(v_field));
 
 	do {
+		uint32_t prev_mb_skipped = 0;
 		/* the scalar cursor is in step with vb here (vb_store at the end of
 		 * the previous macroblock / vb_load above) */
 		vb_sync(vb, wb, lane);
@@ -1322,11 +1501,42 @@ sd_slice_data(WaveBits &wb, const VlcTabs &vt, uint32_t cbp_map, uint32_t lane,
 			vb_store(vb, wb);
 			if (wb_overrun(wb))
 				return -EIO;
+			prev_mb_skipped = run > 0;
 			for (uint32_t r = 0; r < run; r++) {
 				if (mbidx >= mb_capacity)
 					return H264_AMD_E_MB_OVERFLOW;
-				sd_emit_skipped(o, skip_word0, mbidx, lane);
-				sd_next_mb(m, row, stage - SD_DUMP_BYTES, mbx, W, lane);
+				if (MBAFF) {
+					/* field flag of a skipped macroblock (ref
+					 * src/h264_slice_data.c:1150-1172) */
+					uint32_t top = (cur_addr & 1u) ^ 1u, ff;
+					uint32_t above_field;
+					SD_PAIR_NEIGHBOURS();
+					if (top) {
+						ff = 0; /* waits for the bottom one */
+						P.top_skipped = 1;
+					} else if (!P.top_skipped) {
+						ff = P.pair_field;
+					} else {
+						ff = m.availA   ? P.left_field
+						     : m.availB ? above_field
+								: 0u;
+					}
+					P.pair_field = ff;
+					sd_emit_skipped(
+						o,
+						skip_word0 |
+							(ff ? (uint32_t)H264_AMD_MB_FIELD
+									<< 16
+							    : 0u),
+						mbidx, lane);
+					sd_next_mb_mbaff(m, P, row,
+							 stage - SD_DUMP_BYTES, mbx, top,
+							 ff, lane);
+				} else {
+					sd_emit_skipped(o, skip_word0, mbidx, lane);
+					sd_next_mb(m, row, stage - SD_DUMP_BYTES, mbx,
+						   W, lane);
+				}
 				SD_FMO_STEP();
 				mbidx++;
 				mb_count = mbidx;
@@ -1338,15 +1548,36 @@ sd_slice_data(WaveBits &wb, const VlcTabs &vt, uint32_t cbp_map, uint32_t lane,
 			return H264_AMD_E_MB_OVERFLOW;
 
 		/* ---- new macroblock: neighbours, clean record ---- */
+		uint32_t mb_field = 0, mb_top = 1;
+		if (MBAFF) {
+			/* mb_field_decoding_flag: with the top macroblock of a
+			 * pair, or with the bottom one behind a skipped top (ref
+			 * src/h264_syntax_slice_data.h:754-761) */
+			uint32_t above_field;
+			mb_top = (cur_addr & 1u) ^ 1u;
+			if (mb_top || prev_mb_skipped)
+				mb_field = vb_u(vb, wb, 1);
+			else
+				mb_field = P.pair_field;
+			if (mb_top)
+				P.top_skipped = 0;
+			P.pair_field = mb_field;
+			SD_PAIR_NEIGHBOURS();
+			sd_mb_begin_mbaff(m, P, row, mbx, mb_top, mb_field,
+					  above_field);
+		}
+		if (!MBAFF) {
 		m.availA = (mbx != 0 && mbidx >= 1) ? 1u : 0u;
 		m.availB = mbidx >= W ? 1u : 0u;
-		if (fmo) {
+		}
+		if (fmo && !MBAFF) {
 			uint32_t tag = wb_uniform(*reinterpret_cast<const uint32_t *>(
-				row + 16u * mbx + 12u));
+				row + RS * mbx + 12u));
 			m.availA = (mbx != 0 && prev_addr + 1u == cur_addr) ? 1u : 0u;
 			m.availB = (cur_addr >= W && tag == cur_addr - W) ? 1u : 0u;
 		}
-		sd_mb_begin(m, row, mbx, lane);
+		if (!MBAFF)
+			sd_mb_begin(m, row, mbx, lane);
 		/* clean record: the staging area is 4 KiB, zero what the
 		 * largest record (1792 B) can touch */
 		*reinterpret_cast<uint4 *>(stage + 16u * lane) = make_uint4(0, 0, 0, 0);
@@ -1355,6 +1586,17 @@ sd_slice_data(WaveBits &wb, const VlcTabs &vt, uint32_t cbp_map, uint32_t lane,
 				make_uint4(0, 0, 0, 0);
 
 		/* ---- mb_type (ref src/h264_slice_data.c:839-969) ---- */
+		/* ref_idx: present when there is more than one picture to choose
+		 * from -- a field macroblock of an MBAFF frame always has (two
+		 * fields per frame), with twice the range; max_ref_idx is a
+		 * uint8_t in the reference (src/h264_macroblock.h:141-142,
+		 * src/h264_slice_data.c:1199-1205) */
+		const bool ref0_present = S.nref0 > 0 || (MBAFF && mb_field);
+		const bool ref1_present = S.nref1 > 0 || (MBAFF && mb_field);
+		const uint32_t ref0_range =
+			((MBAFF && mb_field) ? 2u * S.nref0 + 1u : S.nref0) & 0xffu;
+		const uint32_t ref1_range =
+			((MBAFF && mb_field) ? 2u * S.nref1 + 1u : S.nref1) & 0xffu;
 		uint32_t raw_type, t, mb_type = 0, nparts = 0;
 		uint32_t pm0 = PM_I4x4, pm1 = PM_I4x4;
 		uint32_t i16pred = 0, cbp_luma = 0, cbp_chroma = 0;
@@ -1499,23 +1741,23 @@ sd_slice_data(WaveBits &wb, const VlcTabs &vt, uint32_t cbp_map, uint32_t lane,
 						no_sub8 = false;
 					}
 				}
-				if (S.nref0 > 0 && mb_type != H264_MB_TYPE_P_8x8ref0) {
+				if (ref0_present && mb_type != H264_MB_TYPE_P_8x8ref0) {
 #pragma unroll
 					for (uint32_t p = 0; p < 4; p++)
 						if (sub_pm[p] != PM_DIRECT &&
 						    sub_pm[p] != PM_L1) {
-							uint32_t r = vb_te(vb, wb, S.nref0, ok);
+							uint32_t r = vb_te(vb, wb, ref0_range, ok);
 							if (!ok)
 								return -EIO;
 							lds_w8(stage, 64 + p, r, lane);
 						}
 				}
-				if (S.nref1 > 0) {
+				if (ref1_present) {
 #pragma unroll
 					for (uint32_t p = 0; p < 4; p++)
 						if (sub_pm[p] != PM_DIRECT &&
 						    sub_pm[p] != PM_L0) {
-							uint32_t r = vb_te(vb, wb, S.nref1, ok);
+							uint32_t r = vb_te(vb, wb, ref1_range, ok);
 							if (!ok)
 								return -EIO;
 							lds_w8(stage, 68 + p, r, lane);
@@ -1560,19 +1802,19 @@ sd_slice_data(WaveBits &wb, const VlcTabs &vt, uint32_t cbp_map, uint32_t lane,
 					if (chroma12)
 						VRD_UE(icp);
 				} else if (pm0 != PM_DIRECT) {
-					if (S.nref0 > 0) {
+					if (ref0_present) {
 						for (uint32_t p = 0; p < nparts; p++)
 							if ((p ? pm1 : pm0) != PM_L1) {
-								uint32_t r = vb_te(vb, wb, S.nref0, ok);
+								uint32_t r = vb_te(vb, wb, ref0_range, ok);
 								if (!ok)
 									return -EIO;
 								lds_w8(stage, 64 + p, r, lane);
 							}
 					}
-					if (S.nref1 > 0) {
+					if (ref1_present) {
 						for (uint32_t p = 0; p < nparts; p++)
 							if ((p ? pm1 : pm0) != PM_L0) {
-								uint32_t r = vb_te(vb, wb, S.nref1, ok);
+								uint32_t r = vb_te(vb, wb, ref1_range, ok);
 								if (!ok)
 									return -EIO;
 								lds_w8(stage, 68 + p, r, lane);
@@ -1718,6 +1960,9 @@ sd_slice_data(WaveBits &wb, const VlcTabs &vt, uint32_t cbp_map, uint32_t lane,
 					 (flags << 16) | ((raw_type & 0xffu) << 24);
 			uint32_t word1 = ((uint32_t)qpd & 0xffffu) |
 					 ((icp & 0xffu) << 16) | (i16pred << 24);
+			if (MBAFF)
+				word0 |= mb_field ? (uint32_t)H264_AMD_MB_FIELD << 16
+						  : 0u;
 			lds_w32(stage, 0, word0 | v_field, lane);
 			lds_w32(stage, 4, word1, lane);
 			/* intra prediction modes are already in place */
@@ -1729,12 +1974,17 @@ sd_slice_data(WaveBits &wb, const VlcTabs &vt, uint32_t cbp_map, uint32_t lane,
 				 lane) = (uint8_t)m.cur;
 		}
 		sd_emit_staged(o, stage, mbidx, lane);
-		sd_next_mb(m, row, stage - SD_DUMP_BYTES, mbx, W, lane);
+		if (MBAFF)
+			sd_next_mb_mbaff(m, P, row, stage - SD_DUMP_BYTES, mbx, mb_top,
+					 mb_field, lane);
+		else
+			sd_next_mb(m, row, stage - SD_DUMP_BYTES, mbx, W, lane);
 		SD_FMO_STEP();
 		mbidx++;
 		mb_count = mbidx;
 	} while (wb_more_rbsp_data(wb, lane));
 #undef SD_FMO_STEP
+#undef SD_PAIR_NEIGHBOURS
 #undef VRD_UE
 #undef VRD_SE
 	return 0;
@@ -1762,11 +2012,13 @@ struct sd_args {
 	uint8_t *fmo_map;
 	uint32_t fmo_stride;
 	uint32_t row_pitch; /* macroblock columns of row context in LDS */
-	/* LDS of one wave: SD_STAGE_OFF + max(SD_STAGE_BYTES, SD_REC_BYTES + 16 *
-	 * row_pitch) */
+	uint32_t row_mbaff; /* 1: 32 bytes per column (MBAFF frames possible) */
+	/* LDS of one wave: SD_STAGE_OFF + max(SD_STAGE_BYTES, SD_REC_BYTES +
+	 * (16 or 32) * row_pitch) */
 	uint32_t wave_lds_bytes;
 };
 
+template <bool WITH_MBAFF>
 __device__ __forceinline__ void sd_kernel_body(const sd_args &a)
 {
 	extern __shared__ __attribute__((aligned(16))) uint8_t lds_all[];
@@ -1797,6 +2049,7 @@ __device__ __forceinline__ void sd_kernel_body(const sd_args &a)
 	S.bdl = S.bdc = 8;
 	S.pcm_chroma = 0;
 	S.t8x8_mode = S.direct8x8 = S.entropy = S.unsupported = 0;
+	S.mbaff = 0;
 	S.fmo = S.fmo_type = S.pps_version = S.frame_mbs_only = 0;
 	S.map_units_h = S.change_cycle = 0;
 	S.change_rate = 1;
@@ -1879,7 +2132,8 @@ __device__ __forceinline__ void sd_kernel_body(const sd_args &a)
 		if ((a.reader_flags & H264_READER_FLAGS_SLICE_DATA) && !S.entropy) {
 			if (S.unsupported) {
 				status = H264_AMD_E_UNSUPPORTED;
-			} else if (S.W == 0 || S.W > a.row_pitch) {
+			} else if (S.W == 0 || S.W > a.row_pitch ||
+				   (S.mbaff && !a.row_mbaff)) {
 				status = H264_AMD_E_UNSUPPORTED;
 			} else {
 				/* slice groups: this slice's macroblock-to-slice-
@@ -1907,13 +2161,24 @@ __device__ __forceinline__ void sd_kernel_body(const sd_args &a)
 					VlcTabs vt;
 					vlc_open(vt, lds_all, lane);
 					uint32_t cbp_map = a.vlc->cbp[lane];
-					if (S.slice_type == H264_SLICE_TYPE_I && !S.fmo)
-						status = sd_slice_data<true>(
+					if (S.mbaff) {
+						/* the engine launches the pair-aware
+						 * build whenever an SPS allows MBAFF */
+						if constexpr (WITH_MBAFF)
+							status = sd_slice_data<false, true>(
+								wb, vt, cbp_map, lane, stage,
+								row, S, o, a.mb_capacity,
+								mb_count, fmo_map, pic_mbs);
+						else
+							status = -ENOSYS;
+					} else if (S.slice_type == H264_SLICE_TYPE_I &&
+						 !S.fmo)
+						status = sd_slice_data<true, false>(
 							wb, vt, cbp_map, lane, stage, row,
 							S, o, a.mb_capacity, mb_count,
 							nullptr, 0);
 					else
-						status = sd_slice_data<false>(
+						status = sd_slice_data<false, false>(
 							wb, vt, cbp_map, lane, stage, row,
 							S, o, a.mb_capacity, mb_count,
 							fmo_map, pic_mbs);
@@ -1975,7 +2240,7 @@ __device__ __forceinline__ void sd_kernel_body(const sd_args &a)
 extern "C" __global__ void __launch_bounds__(64 * SD_WAVES_PER_BLOCK, 4)
 h264_amd_k_decode_slices(sd_args a)
 {
-	sd_kernel_body(a);
+	sd_kernel_body<false>(a);
 }
 
 /* 96 registers, 5 waves per SIMD: more waves to hide one another's latency,
@@ -1983,5 +2248,14 @@ h264_amd_k_decode_slices(sd_args a)
 extern "C" __global__ void __launch_bounds__(64 * SD_WAVES_PER_BLOCK, 5)
 h264_amd_k_decode_slices_w5(sd_args a)
 {
-	sd_kernel_body(a);
+	sd_kernel_body<false>(a);
+}
+
+/* the build that also holds the macroblock-pair walk (MBAFF): launched only
+ * when a parameter set allows it, so that its registers and code are not
+ * carried by the two above */
+extern "C" __global__ void __launch_bounds__(64 * SD_WAVES_PER_BLOCK, 4)
+h264_amd_k_decode_slices_mbaff(sd_args a)
+{
+	sd_kernel_body<true>(a);
 }

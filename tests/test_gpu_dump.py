@@ -171,3 +171,50 @@ def test_dump_text_form_and_object_semantics():
     assert H.h264_dump_get_json_str(d, C.byref(s)) == 0 and s.value == b"{ }"
     assert H.h264_dump_destroy(d) == 0 and H.h264_dump_destroy(None) == 0
     H.h264_ctx_destroy(ctx)
+
+
+def test_dump_mbaff_and_slice_groups():
+    """mbAddr, MbaffFrameFlag and mb_field_decoding_flag of the dump's
+    macroblock items (ref src/h264_syntax_slice_data.h:751-761): the flag
+    shows with a pair's top macroblock, or with the bottom one behind a
+    skipped top; addresses follow the slice group map."""
+    from test_oracle_vs_generator import fmo_cfg
+    cfg, cycle = fmo_cfg(1, field_coding=2)
+    m = gen.slice_group_map(cfg, cycle, 0)
+    nals = [gen.sps(cfg), gen.pps(cfg)]
+    for g in sorted(set(m.tolist())):
+        addrs = np.nonzero(m == g)[0]
+        nals.append(gen.slice_nal(cfg, streams.rich_slice(
+            cfg, 1900 + g, (0, 2, 1)[g % 3], int(addrs[0]) // 2, len(addrs),
+            field_pic=0, pm_skip=300)))
+    data = streams.annexb(nals)
+    ref = orc.parse_stream(data, want=orc.ORC_REC_WANT_T2)
+    got = prod.parse_stream(data, want=prod.WANT_DUMP)
+    lines = [json.loads(x) for x in got.dumps.strip().split("\n")]
+    slices = [j["slice"] for j in lines if "slice" in j]
+    ev = [e for e in ref.event_tuples() if e[0] == 7]
+    assert len(slices) == len(ref.results)
+    k = n_flags = 0
+    for i, js in enumerate(slices):
+        recs = ref.mb_records(i)
+        mi = 0
+        prev_skipped = False
+        for item in js["slice_data"]["mb"]:
+            if "mb_skip_run" in item:
+                mi += item["mb_skip_run"]
+                k += item["mb_skip_run"]
+                prev_skipped = item["mb_skip_run"] > 0
+                continue
+            assert item["mbAddr"] == ev[k][1]
+            assert item["MbaffFrameFlag"] == 1
+            if item["mbAddr"] % 2 == 0 or prev_skipped:
+                assert item["mb_field_decoding_flag"] == \
+                    (int(recs[mi][2]) >> 2) & 1
+                n_flags += 1
+            else:
+                assert "mb_field_decoding_flag" not in item
+            prev_skipped = False
+            mi += 1
+            k += 1
+        assert mi == ref.results[i].mb_count
+    assert k == len(ev) and n_flags > 10
