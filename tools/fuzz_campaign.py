@@ -30,17 +30,54 @@ def one(engine, seed):
                             transform_8x8_mode_flag=rnd.randrange(2),
                             weighted_pred_flag=rnd.randrange(2),
                             weighted_bipred_idc=rnd.randrange(3))
+    # every fourth seed: MBAFF frames; every fourth: slice groups (a random map
+    # type, frame / field / MBAFF pictures); the rest as before
+    mode = ("plain", "mbaff", "fmo", "plain")[seed % 4]
+    cycle = 0
+    if mode == "mbaff":
+        cfg = streams.small_cfg(cf=cf, bd=bd, field_coding=2,
+                                transform_8x8_mode_flag=rnd.randrange(2),
+                                weighted_pred_flag=rnd.randrange(2),
+                                weighted_bipred_idc=rnd.randrange(3))
+    elif mode == "fmo":
+        from test_oracle_vs_generator import FMO_CASES, fmo_cfg
+        cfg, cycle = fmo_cfg(rnd.choice(list(FMO_CASES)), cf=cf, bd=bd,
+                             field_coding=rnd.choice([0, 0, 1, 2]),
+                             transform_8x8_mode_flag=rnd.randrange(2))
     total = cfg.width_mbs * cfg.height_mbs
     nals = []
+    groups = {}
     for k in range(160):
         st = rnd.choice([2, 0, 1, 7, 5, 6, 3, 4])
-        first = rnd.choice([0, 0, rnd.randrange(total - 1)])
-        n = rnd.randrange(1, total - first + 1)
+        kw = {}
+        fp = rnd.randrange(3) if cfg.field_coding == 1 else 0
+        if cfg.field_coding == 2:
+            fp = rnd.choice([0, 0, 1, 2])
+        if cfg.field_coding:
+            kw["field_pic"] = fp
+        pair = cfg.field_coding == 2 and fp == 0
+        if mode == "fmo":
+            # a slice of one group: from one of its addresses to some later one
+            if fp not in groups:
+                groups[fp] = gen.slice_group_map(cfg, cycle, fp)
+            m = groups[fp]
+            addrs = np.nonzero(m == rnd.choice(sorted(set(m.tolist()))))[0]
+            step = 2 if pair else 1
+            i0 = rnd.choice([0, rnd.randrange(len(addrs) // step) * step])
+            first = int(addrs[i0]) // step
+            n = rnd.randrange(1, (len(addrs) - i0) // step + 1) * step
+            kw["slice_group_change_cycle"] = cycle
+        else:
+            units = total  # pairs of an MBAFF frame, macroblocks otherwise
+            first = rnd.choice([0, 0, rnd.randrange(units - 1)])
+            n = rnd.randrange(1, units - first + 1) * (2 if pair else 1)
         s = streams.rich_slice(cfg, seed * 977 + k, st, first, n,
                                density=rnd.randrange(0, 17),
                                pm_escape=rnd.choice([0, 30, 400]),
                                pm_pcm=rnd.choice([0, 30, 300]),
-                               hdr_extras=rnd.randrange(8) if st % 5 != 2 else 0)
+                               pm_skip=rnd.choice([200, 200, 700]),
+                               hdr_extras=rnd.randrange(8) if st % 5 != 2 else 0,
+                               **kw)
         nal = gen.slice_nal(cfg, s)
         nals.append(mutate(nal, rnd) if k % 6 else nal)
     ref = orc.parse_nalus([gen.sps(cfg), gen.pps(cfg)] + nals)
@@ -48,7 +85,7 @@ def one(engine, seed):
     buf, offs, sizes = streams.pack_nals(nals, lead=seed % 5)
     d_buf = engine.upload(buf)
     descs = [(o, s, params.epoch) for o, s in zip(offs, sizes)]
-    cap = 4 * total
+    cap = 8 * total
     out = engine.decode_slices(params, d_buf, descs, reader_flags=1,
                                tier=TIER_T2, mb_capacity=cap,
                                want_headers=True)
