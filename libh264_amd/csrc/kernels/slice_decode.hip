@@ -661,6 +661,34 @@ __device__ __forceinline__ uint32_t sd_fmo_next(const uint8_t *map,
 	}
 }
 
+/* ---- phase timers (diagnostic build only: -DSD_PHASE_TIMERS) -----------------
+ * tools/phase_timers.py: cycles (s_memtime) between consecutive marks, summed
+ * per phase in lane `phase` of one vector register, calls counted next to them;
+ * the sums replace the first 32 T0 words of the slice.  Phase 15 follows phase
+ * 14 directly: the cost of a mark itself. */
+#ifdef SD_PHASE_TIMERS
+struct SdTimers {
+	uint32_t acc, cnt; /* per lane */
+	uint32_t last; /* scalar */
+};
+#define SD_TARG , SdTimers &T
+#define SD_TPASS , T
+#define SD_T(k)                                                                \
+	do {                                                                   \
+		uint32_t t_ = (uint32_t)__builtin_readcyclecounter();          \
+		uint32_t d_ = t_ - T.last;                                     \
+		T.last = t_;                                                   \
+		T.acc += lane == (uint32_t)(k) ? d_ : 0u;                      \
+		T.cnt += lane == (uint32_t)(k) ? 1u : 0u;                      \
+	} while (0)
+#else
+#define SD_TARG
+#define SD_TPASS
+#define SD_T(k)                                                                \
+	do {                                                                   \
+	} while (0)
+#endif
+
 /* ---- macroblock bookkeeping ---------------------------------------------- */
 
 /* Neighbour context of 9.2.1 (nC) kept incrementally.  Lane l = comp * 16 +
@@ -942,7 +970,7 @@ __device__ __forceinline__ uint32_t sd_level_escape(WaveBits &wb, uint32_t lane,
 __device__ __forceinline__ uint32_t
 sd_residual_block(VBits &vb, WaveBits &wb, const VlcTabs &vt, uint32_t lane,
 		  uint8_t *stage, uint32_t cls, uint32_t bits, uint32_t maxnum,
-		  uint32_t coef_off, uint32_t &serr)
+		  uint32_t coef_off, uint32_t &serr SD_TARG)
 {
 	/* ---- coeff_token; bits: the peek at the cursor, which the block loop
 	 * already has ---- */
@@ -957,6 +985,7 @@ sd_residual_block(VBits &vb, WaveBits &wb, const VlcTabs &vt, uint32_t lane,
 		tc = (cw >> 7) & 31u;
 	}
 	vb_skip(vb, len); /* <= 16 bits */
+	SD_T(4);
 	if (tc == 0)
 		return 0;
 	/* ---- trailing ones: bit (t1 - 1 - i) of the sign field is level i, i.e.
@@ -1051,6 +1080,7 @@ sd_residual_block(VBits &vb, WaveBits &wb, const VlcTabs &vt, uint32_t lane,
 			}
 		}
 	}
+	SD_T(5);
 	/* ---- total_zeros and the runs: zl = zerosLeft before run i, per lane ---- */
 	uint32_t zl = 0;
 	uint32_t zeros_left = 0;
@@ -1073,6 +1103,7 @@ sd_residual_block(VBits &vb, WaveBits &wb, const VlcTabs &vt, uint32_t lane,
 	 * zerosLeft <= 6: at most 3 bits, so ten of them fit behind one vb_norm();
 	 * a byte table per class held by lane `class` (vt.rb_lo / rb_hi), entry =
 	 * len << 4 | run picked by the next three bits. */
+	SD_T(6);
 	i = 0;
 	while (i + 1 < tc && zeros_left > 0) {
 		vb_norm(vb, wb);
@@ -1110,6 +1141,7 @@ sd_residual_block(VBits &vb, WaveBits &wb, const VlcTabs &vt, uint32_t lane,
 		} while (i < lim && zeros_left > 0);
 	}
 	zl = wb_setlane(zl, tc - 1u, zeros_left, lane);
+	SD_T(7);
 	/* ---- levelCode -> value (even code -> +(code + 2) / 2, odd ->
 	 * -(code + 1) / 2, as int16), and lane i places coefficient i ---- */
 	uint32_t ng = codes & 1u;
@@ -1124,6 +1156,7 @@ sd_residual_block(VBits &vb, WaveBits &wb, const VlcTabs &vt, uint32_t lane,
 	*reinterpret_cast<uint16_t *>(
 		lds_sel(stage + H264_AMD_T2_HEAD + 2u * (coef_off + pos),
 			stage - SD_DUMP_BYTES, mine, lane)) = (uint16_t)lv;
+	SD_T(8);
 	return tc;
 }
 
@@ -1374,7 +1407,7 @@ __device__ __forceinline__ int
 sd_slice_data(WaveBits &wb, const VlcTabs &vt, uint32_t cbp_map, uint32_t lane,
 	      uint8_t *stage, uint8_t *row, const SliceState &S, OutCtx &o,
 	      uint32_t mb_capacity, uint32_t &mb_count, const uint8_t *fmo_map,
-	      uint32_t pic_mbs)
+	      uint32_t pic_mbs SD_TARG)
 {
 	const uint32_t cat = S.cat, W = S.W;
 	const bool is_si = !ONLY_I && S.slice_type == H264_SLICE_TYPE_SI;
@@ -1548,6 +1581,7 @@ sd_slice_data(WaveBits &wb, const VlcTabs &vt, uint32_t cbp_map, uint32_t lane,
 			return H264_AMD_E_MB_OVERFLOW;
 
 		/* ---- new macroblock: neighbours, clean record ---- */
+		SD_T(0);
 		uint32_t mb_field = 0, mb_top = 1;
 		if (MBAFF) {
 			/* mb_field_decoding_flag: with the top macroblock of a
@@ -1672,6 +1706,7 @@ sd_slice_data(WaveBits &wb, const VlcTabs &vt, uint32_t cbp_map, uint32_t lane,
 		uint32_t flags = 0, icp = 0;
 		int32_t qpd = 0;
 		uint32_t pred_lo = 0, pred_hi = 0; /* pred[8] of the summary */
+		SD_T(1);
 
 		if (mb_type == H264_MB_TYPE_I_PCM) {
 			/* pcm_alignment_zero_bit, then raw samples (:622-645) */
@@ -1833,6 +1868,7 @@ sd_slice_data(WaveBits &wb, const VlcTabs &vt, uint32_t cbp_map, uint32_t lane,
 						}
 				}
 			}
+			SD_T(2);
 			vb_sync(vb, wb, lane);
 			if (pm0 != PM_I16x16) {
 				/* coded_block_pattern, me(v) mapping of Table 9-4
@@ -1860,6 +1896,7 @@ sd_slice_data(WaveBits &wb, const VlcTabs &vt, uint32_t cbp_map, uint32_t lane,
 						flags |= H264_AMD_MB_TRANSFORM_8X8;
 				}
 			}
+			SD_T(3);
 			if (cbp_luma > 0 || cbp_chroma > 0 || pm0 == PM_I16x16) {
 				VRD_SE(qpd);
 				/* ---- residual (:334-419).  The coded blocks
@@ -1886,6 +1923,7 @@ sd_slice_data(WaveBits &wb, const VlcTabs &vt, uint32_t cbp_map, uint32_t lane,
 				}
 				const uint32_t vinfo = i16 ? m.info_i16 : m.info_n;
 				uint32_t serr = 0;
+				SD_T(9);
 				while (todo) {
 					vb_sync(vb, wb, lane);
 					vb_norm(vb, wb);
@@ -1925,6 +1963,7 @@ sd_slice_data(WaveBits &wb, const VlcTabs &vt, uint32_t cbp_map, uint32_t lane,
 								__builtin_amdgcn_readlane(
 									(int)incl, (int)last));
 							todo &= ~fit;
+							SD_T(10);
 							continue;
 						}
 					}
@@ -1938,13 +1977,15 @@ sd_slice_data(WaveBits &wb, const VlcTabs &vt, uint32_t cbp_map, uint32_t lane,
 					 * fuller one); chroma DC blocks have their own */
 					uint32_t cls = vlc_ct_class(sd_nc(m, info >> 24));
 					cls = ((info >> 11) & 3u) ? 3u + cat : cls;
+					SD_T(11);
 					uint32_t tc = sd_residual_block(
 						vb, wb, vt, lane, stage, cls, peek,
 						(info >> 6) & 31u,
-						(info >> 13) & 0x7ffu, serr);
+						(info >> 13) & 0x7ffu, serr SD_TPASS);
 					/* TotalCoeff is recorded for every class, DC
 					 * blocks included (Appendix C.4) */
 					sd_nz_set(m, nzlane, tc, lane);
+					SD_T(12);
 				}
 				if (serr)
 					return -EIO;
@@ -1953,6 +1994,7 @@ sd_slice_data(WaveBits &wb, const VlcTabs &vt, uint32_t cbp_map, uint32_t lane,
 		vb_store(vb, wb);
 		if (wb_overrun(wb))
 			return -EIO;
+		SD_T(13);
 
 		/* ---- summary (struct h264_amd_mb_summary) ---- */
 		{
@@ -1982,6 +2024,8 @@ sd_slice_data(WaveBits &wb, const VlcTabs &vt, uint32_t cbp_map, uint32_t lane,
 		SD_FMO_STEP();
 		mbidx++;
 		mb_count = mbidx;
+		SD_T(14);
+		SD_T(15);
 	} while (wb_more_rbsp_data(wb, lane));
 #undef SD_FMO_STEP
 #undef SD_PAIR_NEIGHBOURS
@@ -2061,6 +2105,10 @@ __device__ __forceinline__ void sd_kernel_body(const sd_args &a)
 
 	int status = 0;
 	uint32_t rflags = 0, mb_count = 0, end_bit = 0;
+#ifdef SD_PHASE_TIMERS
+	SdTimers T;
+	T.acc = T.cnt = T.last = 0;
+#endif
 	OutCtx o;
 	o.tier = a.tier;
 	o.mb_stride = a.mb_stride;
@@ -2161,6 +2209,9 @@ __device__ __forceinline__ void sd_kernel_body(const sd_args &a)
 					VlcTabs vt;
 					vlc_open(vt, lds_all, lane);
 					uint32_t cbp_map = a.vlc->cbp[lane];
+#ifdef SD_PHASE_TIMERS
+					T.last = (uint32_t)__builtin_readcyclecounter();
+#endif
 					if (S.mbaff) {
 						/* the engine launches the pair-aware
 						 * build whenever an SPS allows MBAFF */
@@ -2168,7 +2219,8 @@ __device__ __forceinline__ void sd_kernel_body(const sd_args &a)
 							status = sd_slice_data<false, true>(
 								wb, vt, cbp_map, lane, stage,
 								row, S, o, a.mb_capacity,
-								mb_count, fmo_map, pic_mbs);
+								mb_count, fmo_map, pic_mbs
+									SD_TPASS);
 						else
 							status = -ENOSYS;
 					} else if (S.slice_type == H264_SLICE_TYPE_I &&
@@ -2176,12 +2228,12 @@ __device__ __forceinline__ void sd_kernel_body(const sd_args &a)
 						status = sd_slice_data<true, false>(
 							wb, vt, cbp_map, lane, stage, row,
 							S, o, a.mb_capacity, mb_count,
-							nullptr, 0);
+							nullptr, 0 SD_TPASS);
 					else
 						status = sd_slice_data<false, false>(
 							wb, vt, cbp_map, lane, stage, row,
 							S, o, a.mb_capacity, mb_count,
-							fmo_map, pic_mbs);
+							fmo_map, pic_mbs SD_TPASS);
 					end_bit = wb_pos(wb);
 				}
 			}
@@ -2195,6 +2247,15 @@ __device__ __forceinline__ void sd_kernel_body(const sd_args &a)
 		uint32_t v = (uint32_t)__shfl((int)o.t0acc, (int)l);
 		*reinterpret_cast<uint32_t *>(o.mb_out + (size_t)(base + l) * o.mb_stride) = v;
 	}
+
+#ifdef SD_PHASE_TIMERS
+	if (o.tier == H264_AMD_TIER_T0 && mb_count >= 64u) {
+		if (lane < 16u) {
+			*reinterpret_cast<uint32_t *>(o.mb_out + (size_t)lane * o.mb_stride) = T.acc;
+			*reinterpret_cast<uint32_t *>(o.mb_out + (size_t)(16u + lane) * o.mb_stride) = T.cnt;
+		}
+	}
+#endif
 
 	/* wave reduction of the checksum halves */
 	uint32_t lo = o.lo, hi = o.hi;

@@ -1,0 +1,92 @@
+#!/usr/bin/env python3
+"""Where the decode kernel's cycles go, phase by phase (GPU box):
+
+    tools/build_variant.sh timers -DSD_PHASE_TIMERS -mllvm -structurizecfg-skip-uniform-regions
+    python tools/phase_timers.py [--slices 512]
+
+The diagnostic build sums s_memtime differences between marks per phase and
+leaves them in the first 32 T0 words of every slice (slice_decode.hip,
+SD_PHASE_TIMERS).  Printed per macroblock: cycles and calls per phase, the
+cost of a mark (phase 15) taken off.  One wave per SIMD at --slices <= 1024:
+latencies, not throughput.
+"""
+import argparse
+import json
+import os
+import sys
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+sys.path.insert(0, os.path.join(ROOT, "tests"))
+
+PHASES = ["loop top: sync, overrun", "neighbours, clear, mb_type",
+          "mb_pred (intra modes, chroma mode)", "coded_block_pattern",
+          "coeff_token", "trailing ones + levels", "total_zeros",
+          "run_before", "values + store", "mb_qp_delta + block set-up",
+          "empty-run pass (taken)", "block pick: sync, norm, run test, nC",
+          "nz bookkeeping", "end of blocks: store, overrun",
+          "summary, emit, next_mb", "(mark cost)"]
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--slices", type=int, default=512)
+    ap.add_argument("--lib", default=os.path.join(
+        ROOT, "libh264_amd/lib/variants/libengine_timers.so"))
+    args = ap.parse_args()
+    os.environ["H264_AMD_ENGINE_LIB"] = os.path.abspath(args.lib)
+    import bench
+    import libh264_amd
+    from libh264_amd import gen, Params, shard
+    from libh264_amd.ctypes_abi import TIER_T0
+    import orc
+    n = args.slices
+    eng = libh264_amd.Engine(0)
+    cfg, buf, offs, sizes = bench.make_workload(n, 1, 16)
+    rec = orc.parse_nalus([gen.sps(cfg), gen.pps(cfg)], flags=0, want=0)
+    params = Params()
+    params.put_sps(rec.sps[0])
+    epoch = params.put_pps(rec.pps[0])
+    descs = np.zeros(n, dtype=[("offset", "<u8"), ("size", "<u4"),
+                               ("epoch", "<u4")])
+    descs["offset"], descs["size"], descs["epoch"] = offs, sizes, epoch
+    d_buf, d_descs = eng.upload(buf), eng.upload(descs)
+    out = None
+    for _ in range(2):
+        out = eng.decode_slices(params, d_buf, descs, reader_flags=1,
+                                tier=TIER_T0, mb_capacity=8160,
+                                d_descs=d_descs, outputs=out)
+    ms = eng.last_kernel_ms("decode")
+    acc = np.zeros(16)
+    cnt = np.zeros(16)
+    take = min(n, 64)
+    for i in range(take):
+        w = eng.fetch_mb(out, i, 32).reshape(-1).view(np.uint32)[:32]
+        if i == 0:
+            print('raw', w.tolist(), file=sys.stderr)
+        acc += w[:16]
+        cnt += w[16:]
+    mbs = 8160.0 * take
+    mark = acc[15] / max(cnt[15], 1)
+    print("kernel %.2f ms, %d slices; a mark costs %.1f cycles" %
+          (ms, n, mark))
+    total = 0.0
+    rows = []
+    for k in range(15):
+        net = acc[k] - mark * cnt[k]
+        total += net
+        rows.append((k, PHASES[k], net / mbs, cnt[k] / mbs,
+                     net / max(cnt[k], 1)))
+    for k, name, c, calls, per in rows:
+        print("%2d %-40s %8.1f cyc/MB %5.1f%%  %6.2f calls/MB %7.1f cyc/call"
+              % (k, name, c, 100.0 * c * mbs / total, calls, per))
+    print("sum %.1f cycles per macroblock (marks taken off)" % (total / mbs))
+    print(json.dumps({"slices": n, "kernel_ms": ms, "mark_cycles": mark,
+                      "phases": {PHASES[k]: round(c, 1)
+                                 for k, _, c, _, _ in rows}}))
+
+
+if __name__ == "__main__":
+    main()
