@@ -1049,23 +1049,18 @@ sd_residual_block(VBits &vb, WaveBits &wb, const VlcTabs &vt, uint32_t lane,
 		 * usual updates are applied first and an escape takes them back. */
 		vb_norm(vb, wb);
 		for (; i < tc; i++) {
-			const uint32_t vo0 = vb.vo, sl_in = sl;
 			uint32_t b1 = vb_peek(vb);
 			uint32_t p = (uint32_t)__builtin_clz(b1 | 0x10000u);
 			uint32_t n = p + 1u + sl;
-			uint32_t code = ((p - 1u) << sl) + (b1 >> (32u - n));
-			vb_skip(vb, n); /* <= 21 bits */
-			uint32_t keep = codes;
-			codes = lane == i ? code : codes;
-			uint32_t grown = sl + (p >= 3u ? 1u : 0u);
-			sl = grown < 6u ? grown : 6u;
-			/* p >= 15  <=>  p + 29 >= 44;  vo >= 44: step */
-			uint32_t rare = p + 29u > vb.vo ? p + 29u : vb.vo;
+			const uint32_t vo_after = vb.vo + n; /* n <= 21 bits */
+			/* p >= 15  <=>  p + 29 >= 44;  vo >= 44 behind it: step.
+			 * Tested BEFORE anything is updated, so that neither path
+			 * needs the old values kept aside. */
+			uint32_t rare = p + 29u > vo_after ? p + 29u : vo_after;
 			if (vb_true(rare >= 44u)) {
 				if (vb_true(p >= 15u)) {
 					uint32_t ssl = (uint32_t)
-						__builtin_amdgcn_readfirstlane((int)sl_in);
-					vb.vo = vo0;
+						__builtin_amdgcn_readfirstlane((int)sl);
 					vb_store(vb, wb);
 					uint32_t c2 = sd_level_escape(wb, lane, ssl, 0u,
 								      serr);
@@ -1073,11 +1068,23 @@ sd_residual_block(VBits &vb, WaveBits &wb, const VlcTabs &vt, uint32_t lane,
 					sl = ssl;
 					VB_VREG(sl);
 					VB_VREG(c2);
-					codes = lane == i ? c2 : keep;
+					codes = lane == i ? c2 : codes;
 				} else {
+					uint32_t code = ((p - 1u) << sl) +
+							(b1 >> (32u - n));
+					vb.vo = vo_after;
+					codes = lane == i ? code : codes;
+					uint32_t grown = sl + (p >= 3u ? 1u : 0u);
+					sl = grown < 6u ? grown : 6u;
 					vb_norm(vb, wb);
 				}
+				continue;
 			}
+			uint32_t code = ((p - 1u) << sl) + (b1 >> (32u - n));
+			vb.vo = vo_after;
+			codes = lane == i ? code : codes;
+			uint32_t grown = sl + (p >= 3u ? 1u : 0u);
+			sl = grown < 6u ? grown : 6u;
 		}
 	}
 	SD_T(5);
@@ -1105,7 +1112,10 @@ sd_residual_block(VBits &vb, WaveBits &wb, const VlcTabs &vt, uint32_t lane,
 	 * len << 4 | run picked by the next three bits. */
 	SD_T(6);
 	i = 0;
-	while (i + 1 < tc && zeros_left > 0) {
+	/* (loop conditions as ONE compare of a minimum: "runs still to read and
+	 * zeros still to place") */
+	uint32_t left = tc - 1u;
+	while ((left < zeros_left ? left : zeros_left) != 0u) {
 		vb_norm(vb, wb);
 		if (zeros_left > 6) {
 			zl = wb_setlane(zl, i, zeros_left, lane);
@@ -1124,9 +1134,11 @@ sd_residual_block(VBits &vb, WaveBits &wb, const VlcTabs &vt, uint32_t lane,
 				zeros_left -= over ? zeros_left : run;
 			}
 			i++;
+			left--;
 			continue;
 		}
-		uint32_t lim = tc - 1u < i + 10u ? tc - 1u : i + 10u;
+		uint32_t batch = left < 10u ? left : 10u;
+		left -= batch;
 		do {
 			zl = wb_setlane(zl, i, zeros_left, lane);
 			uint32_t top3 = vb_peek(vb) >> 29;
@@ -1138,7 +1150,9 @@ sd_residual_block(VBits &vb, WaveBits &wb, const VlcTabs &vt, uint32_t lane,
 			vb_skip(vb, e >> 4); /* <= 3 bits */
 			zeros_left -= e & 15u;
 			i++;
-		} while (i < lim && zeros_left > 0);
+			batch--;
+		} while ((batch < zeros_left ? batch : zeros_left) != 0u);
+		left += batch;
 	}
 	zl = wb_setlane(zl, tc - 1u, zeros_left, lane);
 	SD_T(7);
