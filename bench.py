@@ -25,6 +25,10 @@ with it.
       point-to-point scatter of the slice bytes -> decode on every rank ->
       all-gather of the result records (libh264_amd/pipeline.py); strong
       scaling.
+  c5: BASELINE config 5 -- the writer round trip: every rank parses the
+      headers of its own S slices and re-emits them with
+      h264_amd_k_write_slices, byte-identical to the input; weak scaling, no
+      data-path collective.
 
 Prints ONE JSON line (rank 0).  roofline.achieved = slice bytes read per launch
 / median kernel time from HIP events on the launch stream; cpu_baseline = the
@@ -386,9 +390,92 @@ def run_c4(args, dist, rank, world, local_rank, cores):
             "gen_seconds": round(gen_s, 1)}), flush=True)
 
 
+def run_c5(args, dist, rank, world, share, eng, params, d_buf, descs, d_descs,
+           buf, offs, sizes, order, total_bytes):
+    """BASELINE config 5, weak scaling: every rank parses the headers of its
+    own batch and re-emits the slices; a step = the header launch + the write
+    launch; nothing crosses ranks on the data path."""
+    from libh264_amd import shard
+    from libh264_amd.ctypes_abi import TIER_NONE
+    n = len(descs)
+    capn = int(sizes.max()) + 64
+
+    def barrier():
+        eng.sync()
+        if dist is not None:
+            import torch
+            torch.cuda.synchronize()
+            dist.barrier()
+
+    out = eng.decode_slices(params, d_buf, descs, reader_flags=0,
+                            tier=TIER_NONE, want_headers=True, d_descs=d_descs)
+    d_out, ooffs, osizes = eng.write_slices(params, d_buf, out, capn)
+    for _ in range(args.warmup):
+        eng.decode_slices(params, d_buf, descs, reader_flags=0, tier=TIER_NONE,
+                          want_headers=True, d_descs=d_descs, outputs=out)
+        eng.write_slices(params, d_buf, out, capn, fetch=False, d_out=d_out)
+    barrier()
+    w_ms, h_ms = [], []
+    t_start = time.perf_counter()
+    for _ in range(args.steps):
+        eng.decode_slices(params, d_buf, descs, reader_flags=0, tier=TIER_NONE,
+                          want_headers=True, d_descs=d_descs, outputs=out,
+                          sync=False)
+        h_ms.append(eng.last_kernel_ms("decode"))
+        eng.write_slices(params, d_buf, out, capn, fetch=False, d_out=d_out)
+        w_ms.append(eng.last_kernel_ms("write"))
+    barrier()
+    elapsed = time.perf_counter() - t_start
+    coll_dev = "cpu" if share else "cuda"
+    elapsed = shard.max_over_ranks(dist, elapsed, device=coll_dev)
+    # bit-exact vs input: sizes of all, bytes of a sample on every rank
+    d_out, ooffs, osizes = eng.write_slices(params, d_buf, out, capn)
+    if not (osizes == descs["size"].astype(np.int32)).all():
+        raise SystemExit("rank %d: write-back sizes differ" % rank)
+    checked = 0
+    for k in range(0, n, max(1, n // max(1, args.verify))):
+        got = eng.download(d_out, int(osizes[k]), offset=int(ooffs[k]))
+        i = int(order[k])
+        if not np.array_equal(got, buf[int(offs[i]):int(offs[i]) +
+                                      int(sizes[i])]):
+            raise SystemExit("rank %d: re-emitted slice %d differs" % (rank, i))
+        checked += 1
+    (all_bytes,) = shard.sum_over_ranks(dist, [total_bytes], device=coll_dev)
+    if rank == 0:
+        k_ms = float(np.median(w_ms))
+        achieved = 2.0 * total_bytes / (k_ms * 1e-3) / 1e9
+        print(json.dumps({
+            "metric": "bitstream_rewritten_mbit_per_s",
+            "value": round(8.0 * all_bytes * args.steps / elapsed / 1e6, 1),
+            "unit": "Mbit/s", "n_gpus": world, "steps": args.steps,
+            "warmup": args.warmup,
+            "ms_per_step": round(1e3 * elapsed / args.steps, 3),
+            "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+            "dtype": "u8", "data": "synthetic",
+            "config": {
+                "workload": "C5: writer round trip, %d 1080p CAVLC I-slices "
+                            "per GPU: headers parsed (one launch), slices "
+                            "re-emitted by h264_amd_k_write_slices (one "
+                            "launch), byte-identical to the input" % n,
+                "slices_per_gpu": n, "bytes_per_gpu": total_bytes,
+                "parallelism": "slices sharded over %d GPU(s), no data-path "
+                               "collective" % world},
+            "roofline": {
+                "bound": "hbm", "kernel": "h264_amd_k_write_slices",
+                "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS,
+                "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 4),
+                "traffic": None, "kernel_ms": round(k_ms, 4),
+                "kernel_ms_stat": "median of %d launches" % len(w_ms),
+                "algorithmic_bytes": 2 * total_bytes,
+                "header_launch_ms": round(float(np.median(h_ms)), 4)},
+            "cpu_baseline": None,
+            "byte_identical_slices_checked_per_rank": checked,
+        }), flush=True)
+
+
 def main():
     ap = argparse.ArgumentParser()
-    ap.add_argument("--workload", default="c2", choices=["c2", "c4"],
+    ap.add_argument("--workload", default="c2", choices=["c2", "c4", "c5"],
                     help="c2: batch of I-slices (BASELINE config 2, the "
                          "headline); c4: one mixed Annex-B stream through scan "
                          "+ scatter + decode + gather (config 4)")
@@ -486,6 +573,12 @@ def main():
     d_buf = eng.upload(buf)
     d_descs = eng.upload(descs)
     tier = {0: TIER_NONE, 1: TIER_T0, 2: TIER_T1}[args.tier]
+    if args.workload == "c5":
+        run_c5(args, dist, rank, world, share, eng, params, d_buf, descs,
+               d_descs, buf, offs, sizes, order, total_bytes)
+        if dist is not None:
+            dist.destroy_process_group()
+        return
     out = eng.decode_slices(params, d_buf, descs, reader_flags=1, tier=tier,
                             mb_capacity=8160, d_descs=d_descs)
 
