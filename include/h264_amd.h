@@ -125,12 +125,14 @@ static inline uint32_t h264_amd_t2_stride(uint32_t chroma_array_type)
 #define H264_AMD_SR_CABAC 0x0004 /* CABAC slice: data kept raw */
 
 /* Engine-specific status values besides negative errno */
-#define H264_AMD_E_UNSUPPORTED (-ENOSYS) /* MBAFF / FMO; CABAC beyond the subset; absurd widths */
+#define H264_AMD_E_UNSUPPORTED (-ENOSYS) /* CABAC beyond the subset; absurd widths; slice groups on pictures beyond level 6.2 */
 #define H264_AMD_E_MB_OVERFLOW (-EOVERFLOW) /* more MBs than mb_capacity */
 #define H264_AMD_E_BAD_DESC (-EFAULT) /* descriptor outside d_buf_len */
 /* Most macroblocks one slice may deliver (64 pictures of 4096 x 2304): where the
  * drop-in reader stops growing a slice's record area, and where the oracle
- * stops too.  Only a damaged mb_skip_run gets anywhere near. */
+ * stops too.  Only a damaged mb_skip_run gets anywhere near.  Under slice
+ * groups the macroblock ADDRESS runs ahead of the count: a slice also ends with
+ * H264_AMD_E_MB_OVERFLOW when its next address lies this far behind its first. */
 #define H264_AMD_MAX_SLICE_MBS (1u << 22)
 
 /* Widest picture whose slice data is walked, in macroblocks (16896 pixels).

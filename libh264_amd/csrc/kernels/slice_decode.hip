@@ -1467,7 +1467,8 @@ sd_slice_data(WaveBits &wb, const VlcTabs &vt, uint32_t cbp_map, uint32_t lane,
 	const bool fmo = !ONLY_I && S.fmo != 0;
 	/* (first_mb_in_slice counts pairs in an MBAFF frame; with slice groups
 	 * the tags name the TOP macroblock of the last pair of a column) */
-	uint32_t cur_addr = S.first_mb * (MBAFF ? 2u : 1u), prev_addr = 0xffffffffu;
+	const uint32_t first_addr = S.first_mb * (MBAFF ? 2u : 1u);
+	uint32_t cur_addr = first_addr, prev_addr = 0xffffffffu;
 	if (fmo) {
 		for (uint32_t c0 = 0; c0 < W; c0 += 64u) {
 			uint32_t c = c0 + lane < W ? c0 + lane : W - 1u;
@@ -1552,6 +1553,11 @@ sd_slice_data(WaveBits &wb, const VlcTabs &vt, uint32_t cbp_map, uint32_t lane,
 			for (uint32_t r = 0; r < run; r++) {
 				if (mbidx >= mb_capacity)
 					return H264_AMD_E_MB_OVERFLOW;
+				/* under slice groups the address runs ahead of
+				 * the count (h264_amd.h, H264_AMD_MAX_SLICE_MBS) */
+				if (fmo && cur_addr - first_addr >=
+						   H264_AMD_MAX_SLICE_MBS)
+					return H264_AMD_E_MB_OVERFLOW;
 				if (MBAFF) {
 					/* field flag of a skipped macroblock (ref
 					 * src/h264_slice_data.c:1150-1172) */
@@ -1592,6 +1598,8 @@ sd_slice_data(WaveBits &wb, const VlcTabs &vt, uint32_t cbp_map, uint32_t lane,
 				break;
 		}
 		if (mbidx >= mb_capacity)
+			return H264_AMD_E_MB_OVERFLOW;
+		if (fmo && cur_addr - first_addr >= H264_AMD_MAX_SLICE_MBS)
 			return H264_AMD_E_MB_OVERFLOW;
 
 		/* ---- new macroblock: neighbours, clean record ---- */

@@ -191,8 +191,14 @@ int orc_new_macroblock(struct orc_ctx *ctx, uint32_t mbAddr, int skipped,
 	 * synthetic-slice writers with mbAddr below first_mb_in_slice * 2: the
 	 * offset wraps and the reference asks realloc for ~200 GB, which fails
 	 * on one machine and grinds for minutes on another.  Here: -ENOMEM. */
-	if (off >= H264_AMD_MAX_SLICE_MBS)
-		return -ENOMEM;
+	if (off >= H264_AMD_MAX_SLICE_MBS) {
+		/* under slice groups the address runs ahead of the count of
+		 * macroblocks delivered: the slice ends like one that has
+		 * delivered H264_AMD_MAX_SLICE_MBS (h264_amd.h) */
+		uint32_t base = sh->first_mb_in_slice *
+				(1u + (uint32_t)ctx->derived.MbaffFrameFlag);
+		return mbAddr >= base ? H264_AMD_E_MB_OVERFLOW : -ENOMEM;
+	}
 	if ((size_t)off + 1 > ctx->slice.mb_table.maxlen) {
 		size_t nl = ((size_t)off + 1 + 127) & ~(size_t)127;
 		struct orc_mb_info *ni = realloc(ctx->slice.mb_table.info,
@@ -1199,7 +1205,7 @@ static int slice_data_internal(struct h264_bitstream *bs, struct orc_reader *rd)
 		 * (ref :763); its -EINVAL cases cannot arise from this loop, the
 		 * table limit can */
 		res = orc_new_macroblock(ctx, addr, 0, field_flag);
-		if (res == -ENOMEM)
+		if (res == -ENOMEM || res == H264_AMD_E_MB_OVERFLOW)
 			return res;
 		res = macroblock_layer(bs, ctx, ctx->mb);
 		if (res < 0)

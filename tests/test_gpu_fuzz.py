@@ -108,3 +108,17 @@ def test_damaged_slices_at_volume(engine, cf, bd, seed):
             assert np.array_equal(mb, ref.mb_records(i)), i
     assert 60 < n_err < 230  # the mutations do bite, and not always
 
+
+
+@pytest.mark.parametrize("seed", [4070, 4226])
+def test_dropin_fuzz_regressions(seed):
+    """seeds of tools/fuzz_dropin.py that once diverged: a damaged
+    mb_skip_run under slice groups, where the macroblock address runs ahead of
+    the count -- oracle and kernel must end the slice at the same macroblock
+    with the same status (H264_AMD_MAX_SLICE_MBS, include/h264_amd.h)"""
+    import os
+    import sys
+    sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(
+        os.path.abspath(__file__))), "tools"))
+    import fuzz_dropin
+    assert fuzz_dropin.one(seed) is None

@@ -26,8 +26,33 @@ from test_gpu_fuzz import mutate  # noqa: E402
 def one(seed):
     rnd = random.Random(seed)
     cf, bd = rnd.choice([(1, 0), (1, 0), (0, 0), (2, 2), (3, 0)])
-    cfg = streams.small_cfg(cf=cf, bd=bd)
-    nals = streams.mixed_nals(cfg, n_slices=20, seed0=seed * 31)
+    # every fourth seed MBAFF material, every fourth slice groups (any map
+    # type; frame, field or MBAFF pictures)
+    mode = seed % 4
+    if mode == 1:
+        cfg = streams.small_cfg(cf=cf, bd=bd, field_coding=2)
+        nals = streams.mixed_nals(cfg, n_slices=20, seed0=seed * 31)
+    elif mode == 2:
+        from libh264_amd import gen
+        from test_oracle_vs_generator import FMO_CASES, fmo_cfg
+        cfg, cycle = fmo_cfg(rnd.choice(list(FMO_CASES)), cf=cf, bd=bd,
+                             field_coding=rnd.choice([0, 0, 1, 2]))
+        nals = [gen.sps(cfg), gen.pps(cfg)]
+        for pic in range(5):
+            fp = 0 if not cfg.field_coding else rnd.choice([0, 1, 2])
+            pair = cfg.field_coding == 2 and fp == 0
+            if pic % 2 == 0:
+                nals.append(gen.aud(pic % 3))
+            for j, (first, n, _a) in enumerate(
+                    gen.group_slices(cfg, cycle, fp, 1 if pair else 2)):
+                kw = {"field_pic": fp} if cfg.field_coding else {}
+                nals.append(gen.slice_nal(cfg, streams.rich_slice(
+                    cfg, seed * 31 + 7 * pic + j, rnd.choice([2, 0, 1]),
+                    first // 2 if pair else first, n,
+                    slice_group_change_cycle=cycle, **kw)))
+    else:
+        cfg = streams.small_cfg(cf=cf, bd=bd)
+        nals = streams.mixed_nals(cfg, n_slices=20, seed0=seed * 31)
     out = []
     for i, n in enumerate(nals):
         out.append(mutate(n, rnd) if (i >= 2 and rnd.random() < 0.6) else n)
