@@ -143,6 +143,18 @@ static inline uint32_t h264_amd_t2_stride(uint32_t chroma_array_type)
  * alike; their headers are still parsed.  Bounds the per-wave row context. */
 #define H264_AMD_MAX_PIC_WIDTH_MBS 1056u
 
+/* Slice groups (FMO): the macroblock-to-slice-group map of a slice is built
+ * for pictures of up to H264_AMD_FMO_MAX_PIC_MBS macroblocks (what level 6.2
+ * allows) and, for the box-out type (slice_group_map_type 3), of up to
+ * H264_AMD_FMO_MAX_BOX_OUT_UNITS map units; the slice data of larger pictures
+ * -- only a damaged SPS asks for them -- is not walked:
+ * H264_AMD_E_UNSUPPORTED in product and oracle, header still parsed.  (The
+ * reference allocates and fills a map of any size, up to 2^32 entries.)
+ * Type 0 run lengths are summed in 64 bits (the reference's 32-bit sum wraps
+ * for run_length_minus1 = 2^32 - 2 and its loop need not end). */
+#define H264_AMD_FMO_MAX_PIC_MBS 139264u
+#define H264_AMD_FMO_MAX_BOX_OUT_UNITS 32768u
+
 /* Per-slice outcome, 64 bytes.  status mirrors what _h264_read_nalu would
  * have returned for this NAL (0, -EIO, -EINVAL ...). */
 struct h264_amd_slice_result {

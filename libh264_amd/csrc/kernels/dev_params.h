@@ -77,7 +77,7 @@ struct dev_fmo {
 /* largest picture (macroblocks of a frame) the per-slice map scratch is sized
  * for: level 6.2 allows 139264; beyond it slices of a picture with slice
  * groups answer H264_AMD_E_UNSUPPORTED */
-#define DEV_FMO_MAX_MBS 139264u
+#define DEV_FMO_MAX_MBS H264_AMD_FMO_MAX_PIC_MBS
 
 /* which version every id names during one epoch */
 struct dev_epoch {

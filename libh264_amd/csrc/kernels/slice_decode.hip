@@ -496,6 +496,8 @@ sd_slice_header(WaveBits &wb, uint32_t lane, uint8_t *stage, SliceState &S,
  * Returns 0 or H264_AMD_E_UNSUPPORTED (picture too large for the scratch /
  * the LDS image). */
 #define SD_FMO_LDS_UNITS (SD_STAGE_BYTES * 8u)
+static_assert(SD_FMO_LDS_UNITS == H264_AMD_FMO_MAX_BOX_OUT_UNITS,
+	      "box-out bitmap and the documented limit differ");
 
 /* slice group of one map unit, per lane, without a divergent branch (see the
  * note on divergent branches above: loops and switches here are uniform, what

@@ -1161,6 +1161,21 @@ static int slice_data_internal(struct h264_bitstream *bs, struct orc_reader *rd)
 	if (ctx->sps_derived.PicWidthInMbs == 0 ||
 	    ctx->sps_derived.PicWidthInMbs > H264_AMD_MAX_PIC_WIDTH_MBS)
 		return H264_AMD_E_UNSUPPORTED;
+	/* and builds a slice group map of any size (h264_amd.h,
+	 * H264_AMD_FMO_MAX_PIC_MBS) */
+	if (ctx->pps->num_slice_groups_minus1 > 0) {
+		uint64_t units = (uint64_t)ctx->sps_derived.PicWidthInMbs *
+				 (ctx->sps->pic_height_in_map_units_minus1 + 1ull);
+		uint64_t mbs = (ctx->sps->frame_mbs_only_flag ||
+				sh->field_pic_flag)
+				       ? units
+				       : 2 * units;
+		if (mbs > H264_AMD_FMO_MAX_PIC_MBS || units == 0)
+			return H264_AMD_E_UNSUPPORTED;
+		if (ctx->pps->slice_group_map_type == 3 &&
+		    units > H264_AMD_FMO_MAX_BOX_OUT_UNITS)
+			return H264_AMD_E_UNSUPPORTED;
+	}
 
 	if (rd->cbs.slice_data_begin)
 		rd->cbs.slice_data_begin(ctx, sh, rd->userdata);

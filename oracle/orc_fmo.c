@@ -37,10 +37,14 @@ static uint32_t umin(uint32_t a, uint32_t b)
 static void map_type_0(struct orc_ctx *ctx, uint32_t *map, uint32_t n)
 {
 	const struct h264_pps *pps = ctx->pps;
-	uint32_t i = 0, grp, j;
+	/* 64-bit position: run_length_minus1 + 1 is added in 32 bits by the
+	 * reference, wraps for 2^32 - 2 and its loop then need not end
+	 * (h264_amd.h, H264_AMD_FMO_MAX_PIC_MBS) */
+	uint64_t i = 0, j;
+	uint32_t grp;
 	do {
 		for (grp = 0; grp <= pps->num_slice_groups_minus1 && i < n;
-		     i += pps->run_length_minus1[grp++] + 1) {
+		     i += (uint64_t)pps->run_length_minus1[grp++] + 1) {
 			for (j = 0; j <= pps->run_length_minus1[grp] && i + j < n;
 			     j++)
 				map[i + j] = grp;
@@ -165,6 +169,12 @@ int orc_gen_slice_group_map(struct orc_ctx *ctx)
 	uint32_t n = ctx->sps_derived.PicSizeInMapUnits;
 	if (ctx->pps->num_slice_groups_minus1 == 0)
 		return 0;
+	/* slice data of such a picture is not walked (h264_amd.h,
+	 * H264_AMD_FMO_MAX_PIC_MBS): nothing ever looks at its map */
+	if (n > H264_AMD_FMO_MAX_PIC_MBS ||
+	    (ctx->pps->slice_group_map_type == 3 &&
+	     n > H264_AMD_FMO_MAX_BOX_OUT_UNITS))
+		return -E2BIG;
 	if (n > ctx->slice.group_map_maxlen) {
 		uint32_t *nm = realloc(ctx->slice.group_map,
 				       (size_t)n * sizeof(uint32_t));

@@ -522,3 +522,46 @@ def test_mbaff_1080i(engine):
               for k in range(2)]
     run_case(engine, cfg, slices, TIER_T0)
     run_case(engine, cfg, slices, TIER_T2)
+
+
+def test_slice_group_limits(engine):
+    """slice groups on pictures beyond what the map scratch is built for
+    (include/h264_amd.h, H264_AMD_FMO_MAX_PIC_MBS / _BOX_OUT_UNITS): slice data
+    refused with -ENOSYS by kernel and oracle alike, header still parsed; one
+    macroblock row below the limit decodes; type 0 with the longest run length
+    the PPS syntax can carry (the reference's 32-bit sum wraps there)."""
+    from test_oracle_vs_generator import fmo_cfg
+
+    def run(cfg, cycle=0, n=10):
+        s = streams.rich_slice(cfg, 2100, 2, 0, n,
+                               slice_group_change_cycle=cycle, hdr_extras=0)
+        nals = [gen.sps(cfg), gen.pps(cfg), gen.slice_nal(cfg, s)]
+        ref = orc.parse_nalus(nals, flags=1)
+        params = make_params(ref)
+        buf, offs, sizes = streams.pack_nals(nals[2:])
+        out = engine.decode_slices(
+            params, engine.upload(buf), [(offs[0], sizes[0], params.epoch)],
+            reader_flags=1, tier=TIER_T0, mb_capacity=n + 2,
+            want_headers=True)
+        res = engine.fetch_results(out)
+        assert result_fields(res[0]) == result_fields(ref.results[0])
+        return res
+
+    # 1056 x 132 = 139392 macroblocks > 139264; 1056 x 131 fits
+    cfg, _ = fmo_cfg(1)
+    cfg.width_mbs, cfg.height_mbs = 1056, 132
+    res = run(cfg)
+    assert res[0].status == -38 and res[0].flags & 1  # header parsed
+    cfg.height_mbs = 131
+    res = run(cfg)
+    assert res[0].status == 0 and res[0].mb_count == 10
+    # box-out: 182 x 181 = 32942 map units > 32768; 181 x 181 = 32761 fits
+    cfg, cycle = fmo_cfg(3)
+    cfg.width_mbs, cfg.height_mbs = 182, 181
+    assert run(cfg, cycle)[0].status == -38
+    cfg.width_mbs = 181
+    assert run(cfg, cycle)[0].status == 0
+    # interleaved with run_length_minus1 = 2^32 - 2
+    cfg, _ = fmo_cfg(0)
+    cfg.run_length_minus1[1] = 0xfffffffe
+    assert run(cfg)[0].status == 0
