@@ -706,7 +706,8 @@ struct MbCtx {
 	uint32_t left; /* nz_coeff of the previous macroblock */
 	uint32_t sum; /* nA + nB of this lane's block */
 	/* per lane, constant for the slice */
-	uint32_t a_int, b_int; /* lane of the A / B neighbour inside the MB or 0xff */
+	uint64_t dep; /* bits: the lanes of the A / B neighbours INSIDE the MB */
+	uint32_t hasint; /* bit 0: has an inner A neighbour, bit 1: an inner B */
 	uint32_t a_ext; /* lane (previous MB) of an external A neighbour or 0xff */
 	int top_slot; /* row-context byte holding an external B neighbour or -1 */
 	int row_slot; /* row-context byte this lane saves (bottom row) or -1 */
@@ -763,8 +764,9 @@ __device__ __forceinline__ void sd_mb_consts(MbCtx &m, uint32_t lane, uint32_t c
 		top_slot = cy ? -1 : (int)(4u * comp + cx);
 		row_slot = cy == h4 - 1u ? (int)(4u * comp + cx) : -1;
 	}
-	m.a_int = a_int;
-	m.b_int = b_int;
+	m.dep = (a_int != 0xffu ? 1ull << a_int : 0ull) |
+		(b_int != 0xffu ? 1ull << b_int : 0ull);
+	m.hasint = (a_int != 0xffu ? 1u : 0u) | (b_int != 0xffu ? 2u : 0u);
 	m.a_ext = a_ext;
 	m.top_slot = top_slot;
 	m.row_slot = row_slot;
@@ -812,8 +814,8 @@ __device__ __forceinline__ void sd_mb_begin(MbCtx &m, const uint8_t *row,
 	bool extA = m.a_ext != 0xffu && m.availA != 0;
 	bool extB = m.top_slot >= 0 && m.availB != 0;
 	m.sum = (extA ? lv : 0u) + (extB ? tv : 0u);
-	bool hasA = m.a_int != 0xffu || extA;
-	bool hasB = m.b_int != 0xffu || extB;
+	bool hasA = (m.hasint & 1u) != 0 || extA;
+	bool hasB = (m.hasint & 2u) != 0 || extB;
 	m.bothv = (hasA && hasB) ? 1u : 0u;
 }
 
@@ -839,7 +841,14 @@ __device__ __forceinline__ void sd_nz_set(MbCtx &m, uint32_t l, uint32_t tc,
 	uint32_t old = (uint32_t)__builtin_amdgcn_readlane((int)m.cur, (int)l);
 	uint32_t delta = tc - old;
 	m.cur = lane == l ? tc : m.cur;
-	m.sum += (m.a_int == l ? delta : 0u) + (m.b_int == l ? delta : 0u);
+	/* the blocks that have this one as their inner A or B neighbour: one
+	 * shift of the lane's neighbour mask instead of two compare-select pairs */
+	uint32_t bit = (uint32_t)(m.dep >> l);
+	/* bit 0 spread over the word (v_bfe_i32), kept opaque: the optimiser
+	 * would turn the and back into a compare and a select */
+	int32_t msk = (int32_t)(bit << 31) >> 31;
+	asm volatile("" : "+v"(msk));
+	m.sum += (uint32_t)msk & delta;
 }
 
 /* The n (16 or 4) prev_intra_pred_mode_flag / rem_intra_pred_mode pairs of an
@@ -1379,8 +1388,8 @@ __device__ __forceinline__ void sd_mb_begin_mbaff(MbCtx &m, const PairCtx &P,
 	bool extA = m.a_ext != 0xffu && m.availA != 0;
 	bool extB = m.top_slot >= 0 && (own != 0 || m.availB != 0);
 	m.sum = (extA ? lv : 0u) + (extB ? tv : 0u);
-	bool hasA = m.a_int != 0xffu || extA;
-	bool hasB = m.b_int != 0xffu || extB;
+	bool hasA = (m.hasint & 1u) != 0 || extA;
+	bool hasB = (m.hasint & 2u) != 0 || extB;
 	m.bothv = (hasA && hasB) ? 1u : 0u;
 }
 

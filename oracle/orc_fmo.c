@@ -171,10 +171,17 @@ int orc_gen_slice_group_map(struct orc_ctx *ctx)
 		return 0;
 	/* slice data of such a picture is not walked (h264_amd.h,
 	 * H264_AMD_FMO_MAX_PIC_MBS): nothing ever looks at its map */
-	if (n > H264_AMD_FMO_MAX_PIC_MBS ||
-	    (ctx->pps->slice_group_map_type == 3 &&
-	     n > H264_AMD_FMO_MAX_BOX_OUT_UNITS))
-		return -E2BIG;
+	{
+		/* the reference multiplies width and height in 32 bits and
+		 * walks both separately (types 3 and 5): a product that wraps
+		 * is a heap overflow there */
+		uint64_t n64 = (uint64_t)ctx->sps_derived.PicWidthInMbs *
+			       ctx->sps_derived.PicHeightInMapUnits;
+		if (n64 != n || n > H264_AMD_FMO_MAX_PIC_MBS ||
+		    (ctx->pps->slice_group_map_type == 3 &&
+		     n > H264_AMD_FMO_MAX_BOX_OUT_UNITS))
+			return -E2BIG;
+	}
 	if (n > ctx->slice.group_map_maxlen) {
 		uint32_t *nm = realloc(ctx->slice.group_map,
 				       (size_t)n * sizeof(uint32_t));

@@ -28,6 +28,8 @@ def lib():
     if _LIB is None:
         path = os.path.join(ROOT, "oracle", "build", "liboracle.so")
         build()  # make is a no-op when the library is up to date
+        # a sanitizer build of the oracle made elsewhere (debugging aid)
+        path = os.environ.get("H264_ORC_LIB", path)
         L = C.CDLL(path)
         L.orc_rec_new.restype = C.c_void_p
         L.orc_rec_new.argtypes = [C.c_uint32, C.c_uint32]

@@ -270,3 +270,31 @@ def test_mbaff_with_slice_groups():
         want += addrs.tolist()
     rec = roundtrip(cfg, slices)
     assert [e[1] for e in rec.event_tuples() if e[0] == 7] == want
+
+
+def test_slice_group_map_of_a_wrapping_picture_size():
+    """a damaged SPS whose width x height wraps in 32 bits, then a PPS with
+    slice groups: the reference's map types 3 and 5 walk width and height
+    separately over a map sized by the wrapped product (a heap overflow there);
+    the oracle builds no map for pictures beyond the documented limits
+    (include/h264_amd.h) and refuses their slice data.  Found by
+    tools/fuzz_params.py, as a crash of the checker."""
+    cfg = streams.small_cfg()
+    base = orc.parse_nalus([gen.sps(cfg), gen.pps(cfg)])
+    b = orc.Builder()
+    sps = type(base.sps[0]).from_buffer_copy(bytes(base.sps[0]))
+    sps.pic_width_in_mbs_minus1 = 0xfffffffe
+    sps.pic_height_in_map_units_minus1 = 0xfffffffe
+    nals = [b.nalu(3, 7, sps=sps)]
+    for mtype in (3, 4, 5, 2, 0, 1, 6):
+        pps = type(base.pps[0]).from_buffer_copy(bytes(base.pps[0]))
+        pps.num_slice_groups_minus1 = 1
+        pps.slice_group_map_type = mtype
+        pps.slice_group_change_rate_minus1 = 47
+        nals.append(b.nalu(3, 8, sps=sps, pps=pps))
+        nals.append(gen.slice_nal(cfg, streams.rich_slice(cfg, 77, 2, 0, 4,
+                                                          hdr_extras=0)))
+    ref = orc.parse_nalus(nals, flags=1, want=0)
+    assert ref.statuses[0] == 0
+    assert all(s == 0 for s in ref.statuses[1::2])  # the parameter sets
+    assert all(s < 0 for s in ref.statuses[2::2])  # no slice data walked
