@@ -185,18 +185,24 @@ struct h264_amd_slice_result {
 	uint64_t checksum;
 };
 
-/* Checksum: sum over macroblock index m and 16-bit word index w (w < 1024) of
- * the T2 record of term(m * 1024 + w, word).  Zero words contribute nothing,
- * so the sum can be taken over any partition of the record, in any order. */
-static inline uint64_t h264_amd_checksum_term(uint32_t idx, uint16_t word)
+/* Checksum: sum over macroblock index m and dword index j (j < 512) of the T2
+ * record of term(m * 512 + j, dword j of the record, little endian: 16-bit word
+ * 2j in its low half).  Zero dwords contribute nothing, so the sum can be taken
+ * over any partition of the record, in any order.
+ * Low half: the two words weighted by odd 16-bit position weights that are
+ * affine in the index (a kernel steps them with one packed add; two words cost
+ * ONE v_dot2_u32_u16); high half: the sum of the two squares times an odd
+ * 32-bit position weight.  All arithmetic modulo 2^32. */
+#define H264_AMD_CHECKSUM_KP 0x9E35u /* odd */
+#define H264_AMD_CHECKSUM_KB 0xC2B2AE3Du /* odd */
+static inline uint64_t h264_amd_checksum_term(uint32_t g, uint32_t dword)
 {
-	/* both multipliers are affine in idx so that a kernel can step them
-	 * from macroblock to macroblock with one add */
-	uint32_t a = idx * 0x9E3779B1u + 0x85EBCA77u;
-	uint32_t b = idx * 0xC2B2AE3Du + 0x27D4EB2Fu;
-	uint32_t w = word;
-	uint32_t lo = w * a;
-	uint32_t hi = (w * (w + 1u)) * b;
+	uint32_t w0 = dword & 0xffffu, w1 = dword >> 16;
+	uint32_t p0 = ((4u * g + 1u) * H264_AMD_CHECKSUM_KP) & 0xffffu;
+	uint32_t p1 = ((4u * g + 3u) * H264_AMD_CHECKSUM_KP) & 0xffffu;
+	uint32_t b = (2u * g + 1u) * H264_AMD_CHECKSUM_KB;
+	uint32_t lo = w0 * p0 + w1 * p1;
+	uint32_t hi = (w0 * w0 + w1 * w1) * b;
 	return ((uint64_t)hi << 32) | lo;
 }
 /* the two 32-bit halves are summed independently (no carry between them) */

@@ -1185,24 +1185,35 @@ sd_residual_block(VBits &vb, WaveBits &wb, const VlcTabs &vt, uint32_t lane,
 	return tc;
 }
 
-/* checksum terms of 8 consecutive 16-bit words starting at word index idx */
-__device__ __forceinline__ void sd_checksum(const uint4 q, uint32_t idx,
+/* checksum terms (h264_amd_checksum_term, h264_amd.h) of 4 consecutive dwords
+ * starting at dword index g: per dword one v_dot2_u32_u16 against the packed
+ * position weights, one for the two squares, one multiply by the 32-bit weight;
+ * the weights step with one packed / one plain add */
+typedef unsigned short sd_u16x2 __attribute__((ext_vector_type(2)));
+
+__device__ __forceinline__ void sd_checksum(const uint4 q, uint32_t g,
 					    bool valid, uint32_t &lo,
 					    uint32_t &hi)
 {
 	const uint32_t d[4] = {q.x, q.y, q.z, q.w};
-	const uint32_t abase = idx * 0x9E3779B1u + 0x85EBCA77u;
-	const uint32_t bbase = idx * 0xC2B2AE3Du + 0x27D4EB2Fu;
+	/* (4g + 1, 4g + 3) * KP, both modulo 2^16 */
+	const uint32_t x = 4u * g + 1u;
+	sd_u16x2 pos, kp, step;
+	pos.x = (unsigned short)x;
+	pos.y = (unsigned short)(x + 2u);
+	kp.x = kp.y = (unsigned short)H264_AMD_CHECKSUM_KP;
+	step.x = step.y = (unsigned short)(4u * H264_AMD_CHECKSUM_KP);
+	sd_u16x2 p = pos * kp;
+	uint32_t b = (2u * g + 1u) * H264_AMD_CHECKSUM_KB;
 	uint32_t l = 0, h = 0;
 #pragma unroll
 	for (int k = 0; k < 4; k++) {
-		uint32_t w0 = d[k] & 0xffffu, w1 = d[k] >> 16;
-		uint32_t a0 = abase + (uint32_t)(2 * k) * 0x9E3779B1u;
-		uint32_t a1 = a0 + 0x9E3779B1u;
-		uint32_t b0 = bbase + (uint32_t)(2 * k) * 0xC2B2AE3Du;
-		uint32_t b1 = b0 + 0xC2B2AE3Du;
-		l += w0 * a0 + w1 * a1;
-		h += (w0 * (w0 + 1u)) * b0 + (w1 * (w1 + 1u)) * b1;
+		sd_u16x2 w;
+		__builtin_memcpy(&w, &d[k], 4);
+		l = __builtin_amdgcn_udot2(w, p, l, false);
+		h += __builtin_amdgcn_udot2(w, w, 0u, false) * b;
+		p += step;
+		b += 2u * H264_AMD_CHECKSUM_KB;
 	}
 	lo += valid ? l : 0u;
 	hi += valid ? h : 0u;
@@ -1237,7 +1248,7 @@ __device__ __forceinline__ void sd_emit_staged(OutCtx &o, const uint8_t *stage,
 		bool valid = want < o.rec_bytes;
 		uint32_t off = valid ? want : o.rec_bytes - 16u;
 		uint4 q = *reinterpret_cast<const uint4 *>(stage + off);
-		sd_checksum(q, mbidx * 1024u + off / 2u, valid, o.lo, o.hi);
+		sd_checksum(q, mbidx * 512u + off / 4u, valid, o.lo, o.hi);
 		if (o.tier == H264_AMD_TIER_T2)
 			*reinterpret_cast<uint4 *>(
 				o.mb_out + (size_t)mbidx * o.mb_stride + off) = q;
@@ -1256,7 +1267,7 @@ __device__ __forceinline__ void sd_emit_staged(OutCtx &o, const uint8_t *stage,
 __device__ __forceinline__ void sd_emit_skipped(OutCtx &o, uint32_t word0,
 						uint32_t mbidx, uint32_t lane)
 {
-	sd_checksum(make_uint4(word0, 0, 0, 0), mbidx * 1024u, lane == 0, o.lo,
+	sd_checksum(make_uint4(word0, 0, 0, 0), mbidx * 512u, lane == 0, o.lo,
 		    o.hi);
 	if (o.tier == H264_AMD_TIER_T2) {
 		for (uint32_t part = 0; part * 1024u < o.rec_bytes; part++) {

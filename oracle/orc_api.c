@@ -191,12 +191,13 @@ static void cb_sd_mb(struct orc_ctx *ctx, const struct h264_slice_header *sh,
 	(void)sh;
 	ev_push(&r->events, EV_SLICE_DATA_MB, mb_addr, mb_type, 0);
 	orc_mb_to_record(ctx, tmp, stride);
-	for (i = 0; i < stride / 2; i++) {
-		if (w[i] != 0)
+	for (i = 0; i < stride / 4; i++) {
+		uint32_t dword = (uint32_t)w[2 * i] | ((uint32_t)w[2 * i + 1] << 16);
+		if (dword != 0)
 			r->cur_sum = h264_amd_checksum_add(
 				r->cur_sum,
-				h264_amd_checksum_term(r->cur_mbs * 1024u + i,
-						       w[i]));
+				h264_amd_checksum_term(r->cur_mbs * 512u + i,
+						       dword));
 	}
 	/* full records only for the first ORC_REC_T2_CAP macroblocks of a slice:
 	 * a damaged skip run would otherwise cost a KiB per phantom macroblock */
