@@ -1473,6 +1473,50 @@ sd_slice_data(WaveBits &wb, const VlcTabs &vt, uint32_t cbp_map, uint32_t lane,
 	m.availA = m.availB = 0;
 	m.bothv = 0;
 	sd_mb_consts(m, lane, cat);
+	/* Residual blocks of a macroblock as a mask over the steps (bit = step in
+	 * bitstream order, src/h264_syntax_slice_data.h:334-419), for every
+	 * coded_block_pattern at once: lane = CodedBlockPatternLuma |
+	 * CodedBlockPatternChroma << 4.  Luma bit k covers blocks 4k .. 4k + 3 of
+	 * each luma-like component (steps 1 .. 16 behind the component's DC
+	 * step); chroma 1 / 2: the two DC blocks, 2: the AC blocks too. */
+	uint32_t todo_lo, todo_hi;
+	{
+		const uint32_t cl = lane & 15u, cc = (lane >> 4) & 3u;
+		uint32_t e16 = ((cl & 1u) | ((cl & 2u) << 3) | ((cl & 4u) << 6) |
+				((cl & 8u) << 9)) * 15u;
+		uint64_t per_comp = (uint64_t)e16 << 1;
+		uint64_t t = per_comp;
+		if (cat == 3)
+			t |= (per_comp << 17) | (per_comp << 34);
+		if (chroma12) {
+			uint64_t c = 0;
+			if (cc & 3u)
+				c |= 3u;
+			if (cc & 2u)
+				c |= ((1ull << (2u * nchroma)) - 1ull) << 2;
+			t |= c << 17;
+		}
+		todo_lo = (uint32_t)t;
+		todo_hi = (uint32_t)(t >> 32);
+	}
+	/* Table 7-11 (mb_type of I slices): lane = value; mb_type | prediction
+	 * mode << 4 | partitions << 7 | Intra16x16PredMode << 8 |
+	 * CodedBlockPatternLuma << 10 | CodedBlockPatternChroma << 14 */
+	uint32_t itab;
+	{
+		const uint32_t t1 = lane - 1u;
+		uint32_t i16e = (uint32_t)H264_MB_TYPE_I_16x16 |
+				((uint32_t)PM_I16x16 << 4) | (1u << 7) |
+				((t1 & 3u) << 8) | ((lane <= 12u ? 0u : 15u) << 10) |
+				(((t1 >> 2) % 3u) << 14);
+		itab = lane == 0   ? (uint32_t)H264_MB_TYPE_I_NxN |
+					   ((uint32_t)PM_I4x4 << 4) | (1u << 7)
+		       : lane <= 24 ? i16e
+				    : (uint32_t)H264_MB_TYPE_I_PCM |
+					      ((uint32_t)PM_I4x4 << 4);
+	}
+	/* the Intra16x16 DC step of every luma-like component */
+	const uint64_t dc_steps = cat == 3 ? 1ull | (1ull << 17) | (1ull << 34) : 1ull;
 	uint32_t mbx = S.first_mb % W;
 	uint32_t mbidx = 0;
 	/* bytes of row context per macroblock column */
@@ -1728,23 +1772,18 @@ sd_slice_data(WaveBits &wb, const VlcTabs &vt, uint32_t cbp_map, uint32_t lane,
 			}
 		}
 		if (intra) {
-			if (t == 0) {
-				mb_type = H264_MB_TYPE_I_NxN;
-				nparts = 1;
-				pm0 = PM_I4x4;
-			} else if (t <= 24) {
-				mb_type = H264_MB_TYPE_I_16x16;
-				nparts = 1;
-				pm0 = PM_I16x16;
-				i16pred = (t - 1u) & 3u;
-				cbp_luma = t <= 12 ? 0u : 15u;
-				cbp_chroma = ((t - 1u) >> 2) % 3u;
-			} else if (t == 25) {
-				mb_type = H264_MB_TYPE_I_PCM;
-				nparts = 0;
-			} else {
+			/* Table 7-11 from the table the lanes hold (lane = mb_type
+			 * value): no chain of compares */
+			if (t > 25)
 				return -EIO;
-			}
+			uint32_t e = (uint32_t)__builtin_amdgcn_readlane((int)itab,
+									  (int)t);
+			mb_type = e & 15u;
+			pm0 = (e >> 4) & 7u;
+			nparts = (e >> 7) & 1u;
+			i16pred = (e >> 8) & 3u;
+			cbp_luma = (e >> 10) & 15u;
+			cbp_chroma = (e >> 14) & 3u;
 		}
 
 		uint32_t flags = 0, icp = 0;
@@ -1948,23 +1987,17 @@ sd_slice_data(WaveBits &wb, const VlcTabs &vt, uint32_t cbp_map, uint32_t lane,
 				 * bitstream order); blocks that are not coded cost
 				 * nothing ---- */
 				const bool i16 = pm0 == PM_I16x16;
-				const uint32_t ncomp = cat == 3 ? 3u : 1u;
-				/* cbp_luma bit k covers blocks 4k..4k+3 */
-				uint32_t e16 = ((cbp_luma & 1u) | ((cbp_luma & 2u) << 3) |
-						((cbp_luma & 4u) << 6) |
-						((cbp_luma & 8u) << 9)) * 15u;
-				uint64_t per_comp = ((uint64_t)e16 << 1) | (i16 ? 1u : 0u);
-				uint64_t todo = per_comp;
-				if (ncomp == 3)
-					todo |= (per_comp << 17) | (per_comp << 34);
-				if (chroma12) {
-					uint64_t c = 0;
-					if (cbp_chroma & 3u)
-						c |= 3u;
-					if (cbp_chroma & 2u)
-						c |= ((1ull << (2u * nchroma)) - 1ull) << 2;
-					todo |= c << 17;
-				}
+				/* the block mask of this coded_block_pattern from
+				 * the table the lanes hold (lane = pattern), the
+				 * Intra16x16 DC block(s) on top */
+				const uint32_t pat = cbp_luma | (cbp_chroma << 4);
+				uint64_t todo =
+					((uint64_t)(uint32_t)__builtin_amdgcn_readlane(
+						 (int)todo_hi, (int)pat)
+					 << 32) |
+					(uint32_t)__builtin_amdgcn_readlane((int)todo_lo,
+									    (int)pat);
+				todo |= i16 ? dc_steps : 0ull;
 				const uint32_t vinfo = i16 ? m.info_i16 : m.info_n;
 				uint32_t serr = 0;
 				SD_T(9);

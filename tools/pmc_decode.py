@@ -33,6 +33,9 @@ def main():
     ap.add_argument("--slices", type=int, default=1024)
     ap.add_argument("--lib", default="")
     ap.add_argument("--out", default="/tmp/pmc_decode")
+    ap.add_argument("--mix", default="",
+                    help="a macroblock mix of tools/bench_mix.py instead of the "
+                         "bench batch")
     args = ap.parse_args()
     env = dict(os.environ, TMPDIR="/tmp")
     if args.lib:
@@ -41,10 +44,13 @@ def main():
     for gi, grp in enumerate(GROUPS):
         d = "%s_%d" % (args.out, gi)
         subprocess.run(["rm", "-rf", d])
+        prog = [os.path.join(ROOT, "tools", "ab_decode.py"), "--child",
+                "--slices", str(args.slices), "--steps", "1"]
+        if args.mix:
+            prog = [os.path.join(ROOT, "tools", "bench_mix.py"), "--only",
+                    args.mix, "--slices", str(args.slices), "--reps", "1"]
         cmd = ["rocprofv3", "--kernel-trace", "--pmc"] + grp + \
-            ["--output-format", "csv", "-d", d, "--", sys.executable,
-             os.path.join(ROOT, "tools", "ab_decode.py"), "--child",
-             "--slices", str(args.slices), "--steps", "1"]
+            ["--output-format", "csv", "-d", d, "--", sys.executable] + prog
         p = subprocess.run(cmd, cwd="/tmp", env=env, stdout=subprocess.PIPE,
                            stderr=subprocess.STDOUT, text=True)
         if p.returncode != 0:
@@ -64,7 +70,7 @@ def main():
                 res[c] /= n[c]  # per launch
     mbs = 8160.0 * args.slices
     out = {"slices": args.slices, "lib": os.path.basename(args.lib) or
-           "in-tree"}
+           "in-tree", "mix": args.mix or "bench batch"}
     for c, v in res.items():
         out[c + "_per_mb"] = round(v / mbs, 2)
     print(json.dumps(out))
