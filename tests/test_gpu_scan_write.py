@@ -303,3 +303,18 @@ def test_byte_stream_to_avcc(engine):
         assert got == want.raw, (len(data), data[:12])
         assert engine.download(d_buf, 64, offset=len(data)).tobytes() == \
             b"\xff" * 64
+
+
+@pytest.mark.parametrize("case", [3, 4, 5, 1])
+def test_write_roundtrip_slice_groups_and_mbaff(engine, case):
+    """write-back of slices under slice groups (slice_group_change_cycle is
+    re-encoded with the width the picture size and the change rate give it,
+    ref src/h264_syntax.h:1352-1372) and of MBAFF frames: byte-identical"""
+    from test_oracle_vs_generator import fmo_cfg, fmo_slices, mbaff_slices
+    cfg, cycle = fmo_cfg(case)
+    roundtrip_case(engine, cfg, [s for s, _ in fmo_slices(cfg, cycle, 2300)])
+    cfg, cycle = fmo_cfg(case, field_coding=1)
+    roundtrip_case(engine, cfg, [s for s, _ in
+                                 fmo_slices(cfg, cycle, 2400, field_pic=1)])
+    cfg = streams.small_cfg(field_coding=2)
+    roundtrip_case(engine, cfg, mbaff_slices(cfg, 2500, n=6))
