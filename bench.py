@@ -81,6 +81,30 @@ def make_workload(n_slices, seed0, threads):
             np.concatenate(sizes))
 
 
+_RESULT_FD = None
+
+
+def keep_stdout_for_the_result():
+    """The contract is ONE JSON line on stdout.  Libraries under us write
+    there too (RCCL prints a version banner when its first communicator comes
+    up): from here on fd 1 goes where fd 2 goes, and the result line is written
+    to a copy of the original fd 1 by emit()."""
+    global _RESULT_FD
+    if _RESULT_FD is None:
+        sys.stdout.flush()
+        _RESULT_FD = os.dup(1)
+        os.dup2(2, 1)
+
+
+def emit(obj):
+    data = (json.dumps(obj) + "\n").encode()
+    if _RESULT_FD is None:
+        sys.stdout.write(data.decode())
+        sys.stdout.flush()
+    else:
+        os.write(_RESULT_FD, data)
+
+
 def spawn_ranks(args):
     """`python bench.py --gpus N` without a launcher: start the N ranks.  This
     process has not imported torch or touched HIP (a process that has must not
@@ -352,7 +376,7 @@ def run_c4(args, dist, rank, world, local_rank, cores):
         slice_bytes = int(plan.descs["size"].sum())
         ms_step = 1e3 * elapsed / args.steps
         per = max(1, -(-n // world))
-        print(json.dumps({
+        emit({
             "metric": "bitstream_parsed_mbit_per_s",
             "value": round(8.0 * len(data) * args.steps / elapsed / 1e6, 1),
             "unit": "Mbit/s", "n_gpus": world, "steps": args.steps,
@@ -387,7 +411,7 @@ def run_c4(args, dist, rank, world, local_rank, cores):
                         "one 1080p slice" % (per, per / 256.0)},
             "cpu_baseline": None,
             "verified_slices_vs_oracle": verified,
-            "gen_seconds": round(gen_s, 1)}), flush=True)
+            "gen_seconds": round(gen_s, 1)})
 
 
 def run_c5(args, dist, rank, world, share, eng, params, d_buf, descs, d_descs,
@@ -444,7 +468,7 @@ def run_c5(args, dist, rank, world, share, eng, params, d_buf, descs, d_descs,
     if rank == 0:
         k_ms = float(np.median(w_ms))
         achieved = 2.0 * total_bytes / (k_ms * 1e-3) / 1e9
-        print(json.dumps({
+        emit({
             "metric": "bitstream_rewritten_mbit_per_s",
             "value": round(8.0 * all_bytes * args.steps / elapsed / 1e6, 1),
             "unit": "Mbit/s", "n_gpus": world, "steps": args.steps,
@@ -470,7 +494,7 @@ def run_c5(args, dist, rank, world, share, eng, params, d_buf, descs, d_descs,
                 "header_launch_ms": round(float(np.median(h_ms)), 4)},
             "cpu_baseline": None,
             "byte_identical_slices_checked_per_rank": checked,
-        }), flush=True)
+        })
 
 
 def main():
@@ -499,6 +523,7 @@ def main():
 
     if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
         sys.exit(spawn_ranks(args))
+    keep_stdout_for_the_result()
 
     from libh264_amd import shard
     rank, world, local_rank = shard.rank_env(gpus=args.gpus)
@@ -767,7 +792,7 @@ def main():
         }
         if side:
             line["side"] = side
-        print(json.dumps(line), flush=True)
+        emit(line)
     if dist is not None:
         dist.destroy_process_group()
 
