@@ -783,11 +783,19 @@ int h264_reader_parse_nalu(struct h264_reader *rd, uint32_t flags,
 		res = run(rd, flags, buf, &nal, 1, 0, NULL, &fatal);
 		return fatal < 0 ? fatal : res;
 	}
-	res = h264_host_engine(&eng);
-	if (res < 0)
-		return res; /* no engine, no slice path: not even this one */
-	if (h264_host_slice_is_header_only(rd->ctx, flags, buf, len) &&
-	    getenv("H264_AMD_NO_HOST_HEADERS") == NULL) {
+	const int header_only =
+		h264_host_slice_is_header_only(rd->ctx, flags, buf, len) &&
+		getenv("H264_AMD_NO_HOST_HEADERS") == NULL;
+	/* no engine, no slice path: not even the header-only one -- except for
+	 * the sanitizer run of the host parser, which has no GPU to offer
+	 * (tests/helpers/fuzz_ctl.c sets the variable; nothing else does) */
+	if (!(header_only &&
+	      getenv("H264_AMD_TEST_HEADERS_WITHOUT_ENGINE") != NULL)) {
+		res = h264_host_engine(&eng);
+		if (res < 0)
+			return res;
+	}
+	if (header_only) {
 		/* one slice whose data nobody looks at: a few dozen bytes of
 		 * header are read here instead of crossing PCIe twice around a
 		 * kernel launch (slicehdr.c) */
