@@ -1059,19 +1059,26 @@ sd_residual_block(VBits &vb, WaveBits &wb, const VlcTabs &vt, uint32_t lane,
 		 * rare events, the escape (prefix >= 15) and the window step: the
 		 * usual updates are applied first and an escape takes them back. */
 		vb_norm(vb, wb);
-		for (; i < tc; i++) {
-			uint32_t b1 = vb_peek(vb);
+		/* lane i of `codes` takes the level: the lane mask comes from the
+		 * scalar side (one s_lshl_b64 per level) instead of a v_cmp into
+		 * VCC with its wait states before the select */
+		uint64_t imask = 1ull << i;
+		for (; i < tc; i++, imask <<= 1) {
+			/* (raw peek: the test below is a 32-bit one already) */
+			uint32_t b1 = (uint32_t)((vb.W << vb.vo) >> 32);
 			uint32_t p = (uint32_t)__builtin_clz(b1 | 0x10000u);
 			uint32_t n = p + 1u + sl;
-			const uint32_t vo_after = vb.vo + n; /* n <= 21 bits */
-			/* p >= 15  <=>  p + 29 >= 44;  vo >= 44 behind it: step.
-			 * Tested BEFORE anything is updated, so that neither path
-			 * needs the old values kept aside. */
-			uint32_t rare = p + 29u > vo_after ? p + 29u : vo_after;
+			/* p >= 15  <=>  p + 29 >= 44;  vo >= 44 behind the level:
+			 * step.  The cursor moves first and an escape takes it
+			 * back: no copy of the old offset is carried. */
+			vb.vo += n; /* n <= 21 bits */
+			const uint32_t p29 = p + 29u;
+			uint32_t rare = p29 > vb.vo ? p29 : vb.vo;
 			if (vb_true(rare >= 44u)) {
 				if (vb_true(p >= 15u)) {
 					uint32_t ssl = (uint32_t)
 						__builtin_amdgcn_readfirstlane((int)sl);
+					vb.vo -= n;
 					vb_store(vb, wb);
 					uint32_t c2 = sd_level_escape(wb, lane, ssl, 0u,
 								      serr);
@@ -1083,7 +1090,6 @@ sd_residual_block(VBits &vb, WaveBits &wb, const VlcTabs &vt, uint32_t lane,
 				} else {
 					uint32_t code = ((p - 1u) << sl) +
 							(b1 >> (32u - n));
-					vb.vo = vo_after;
 					codes = lane == i ? code : codes;
 					uint32_t grown = sl + (p >= 3u ? 1u : 0u);
 					sl = grown < 6u ? grown : 6u;
@@ -1092,9 +1098,12 @@ sd_residual_block(VBits &vb, WaveBits &wb, const VlcTabs &vt, uint32_t lane,
 				continue;
 			}
 			uint32_t code = ((p - 1u) << sl) + (b1 >> (32u - n));
-			vb.vo = vo_after;
-			codes = lane == i ? code : codes;
-			uint32_t grown = sl + (p >= 3u ? 1u : 0u);
+			asm("v_cndmask_b32 %0, %0, %1, %2"
+			    : "+v"(codes)
+			    : "v"(code), "s"(imask));
+			/* + 1 iff p >= 3, without a compare: p + 29 is 29 .. 31
+			 * for p < 3 and 32 .. 43 up to p = 14 */
+			uint32_t grown = sl + (p29 >> 4) - 1u;
 			sl = grown < 6u ? grown : 6u;
 		}
 	}
