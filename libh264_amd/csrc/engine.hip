@@ -86,6 +86,7 @@ struct h264_amd_params {
 
 struct h264_amd_engine {
 	int device;
+	uint32_t cu_count;
 	hipStream_t stream;
 	bool own_stream;
 	dev_vlc_tables *d_vlc;
@@ -237,6 +238,15 @@ extern "C" int h264_amd_engine_new(int device, void *hip_stream,
 		}                                                              \
 	} while (0)
 	e->device = device;
+	{
+		/* workgroups are dispatched in layers of one per compute unit:
+		 * the decode kernel derives a wave's age rank from it */
+		int cus = 0;
+		NEW_TRY(hipDeviceGetAttribute(&cus,
+					      hipDeviceAttributeMultiprocessorCount,
+					      device));
+		e->cu_count = cus > 0 ? (uint32_t)cus : 1u;
+	}
 	if (hip_stream != NULL) {
 		e->stream = (hipStream_t)hip_stream;
 	} else {
@@ -721,6 +731,9 @@ extern "C" int h264_amd_decode_slices(struct h264_amd_engine *e,
 	e->fmo_n = a.fmo_map ? a.n : 0;
 
 	a.row_mbaff = params->any_mbaff ? 1u : 0u;
+	a.prio_div = (a.n + SD_WAVES_PER_BLOCK - 1) / SD_WAVES_PER_BLOCK > e->cu_count
+			     ? e->cu_count
+			     : 0u;
 	{
 		uint32_t tail = SD_REC_BYTES +
 				(a.row_mbaff ? SD_ROW_STRIDE_MBAFF : 16u) * a.row_pitch;

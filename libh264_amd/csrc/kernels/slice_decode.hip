@@ -78,6 +78,8 @@ struct SliceState {
 	uint32_t mbaff; /* MbaffFrameFlag */
 	uint32_t fmo; /* num_slice_groups_minus1 (0: none) */
 	uint32_t fmo_type, pps_version, frame_mbs_only, map_units_h;
+	uint32_t prio_slot; /* age rank of the wave on its SIMD, modulo 4 */
+	uint32_t prio_on; /* 0: the launch fits one dispatch layer, no rotation */
 	uint32_t change_cycle, change_rate;
 	/* header */
 	uint32_t slice_type, first_mb, nref0, nref1, field_pic;
@@ -672,6 +674,7 @@ __device__ __forceinline__ uint32_t sd_fmo_next(const uint8_t *map,
 struct SdTimers {
 	uint32_t acc, cnt; /* per lane */
 	uint32_t last; /* scalar */
+	uint64_t t0, r0; /* scalar: shader clock and 100 MHz clock at the start */
 };
 #define SD_TARG , SdTimers &T
 #define SD_TPASS , T
@@ -689,6 +692,13 @@ struct SdTimers {
 #define SD_T(k)                                                                \
 	do {                                                                   \
 	} while (0)
+#endif
+
+/* RBSP bytes a wave spends at one issue priority before it steps to the next
+ * (see the slice-data loop): 1 << shift, a multiple of the 128-byte window
+ * slide */
+#ifndef SD_PRIO_SHIFT
+#define SD_PRIO_SHIFT 7
 #endif
 
 /* ---- macroblock bookkeeping ---------------------------------------------- */
@@ -1447,6 +1457,38 @@ __device__ __forceinline__ void sd_next_mb_mbaff(MbCtx &m, PairCtx &P, uint8_t *
  * carried through it in registers. */
 /* MBAFF: instantiated for the slices of MBAFF frames (never with ONLY_I):
  * macroblock pairs, see PairCtx */
+/* vb_sync() with the priority step (see the slice-data loop) in its taken
+ * branch */
+__device__ __forceinline__ void sd_vb_sync(VBits &b, WaveBits &s, uint32_t lane,
+					   const SliceState &S)
+{
+	if (b.sd >= WB_SLIDE_BITS / 32u) {
+		vb_store(b, s);
+		wb_sync(s, lane);
+		vb_load(b, s);
+#ifndef SD_NO_PRIO_ROTATION
+		if (S.prio_on) {
+			/* base: RBSP byte index of the window start, 128 more
+			 * per slide */
+			switch (((s.base >> SD_PRIO_SHIFT) + S.prio_slot) & 3u) {
+			case 0:
+				__builtin_amdgcn_s_setprio(0);
+				break;
+			case 1:
+				__builtin_amdgcn_s_setprio(1);
+				break;
+			case 2:
+				__builtin_amdgcn_s_setprio(2);
+				break;
+			default:
+				__builtin_amdgcn_s_setprio(3);
+				break;
+			}
+		}
+#endif
+	}
+}
+
 template <bool ONLY_I, bool MBAFF>
 __device__ __forceinline__ int
 sd_slice_data(WaveBits &wb, const VlcTabs &vt, uint32_t cbp_map, uint32_t lane,
@@ -1608,11 +1650,25 @@ sd_slice_data(WaveBits &wb, const VlcTabs &vt, uint32_t cbp_map, uint32_t lane,
 	uint32_t v_field = field_flag << 16;
 	asm volatile("" : "+v"(v_field));
 
+	/* Fair shares of the SIMD.  The instruction arbiter of a SIMD serves the
+	 * OLDEST wave first when priorities are equal: of the four waves of a full
+	 * launch the first dispatched then runs almost as if alone and the last
+	 * one takes half as long again, which is when the kernel ends -- with
+	 * three, two, one wave left on the SIMD for the last third of the time
+	 * (tools/phase_timers.py prints the waves' own wall times by quarter of
+	 * the batch: 50.8 / 56.5 / 64.4 / 75.0 ms).  So every wave steps its own
+	 * priority round the four levels, offset by its age rank (workgroups are
+	 * dispatched in order, one layer of them per pass over the compute
+	 * units: S.prio_slot): a step whenever the bit window slides (sd_vb_sync:
+	 * 1024 bits of slice data, about six macroblocks -- a branch that exists
+	 * anyway), so every wave spends the same share of its
+	 * bits at every level and all four finish together.  62.4 -> 54.4 ms for
+	 * the bench batch. */
 	do {
 		uint32_t prev_mb_skipped = 0;
 		/* the scalar cursor is in step with vb here (vb_store at the end of
 		 * the previous macroblock / vb_load above) */
-		vb_sync(vb, wb, lane);
+		sd_vb_sync(vb, wb, lane, S);
 		if (wb_overrun(wb))
 			return -EIO;
 		if (!is_i) {
@@ -1897,7 +1953,7 @@ sd_slice_data(WaveBits &wb, const VlcTabs &vt, uint32_t cbp_map, uint32_t lane,
 						if (sub_pm[p] == PM_DIRECT ||
 						    sub_pm[p] == (l ? PM_L0 : PM_L1))
 							continue;
-						vb_sync(vb, wb, lane);
+						sd_vb_sync(vb, wb, lane, S);
 						for (uint32_t s = 0; s < sub_n[p]; s++)
 							for (uint32_t c = 0; c < 2; c++) {
 								int32_t d;
@@ -1961,7 +2017,7 @@ sd_slice_data(WaveBits &wb, const VlcTabs &vt, uint32_t cbp_map, uint32_t lane,
 				}
 			}
 			SD_T(2);
-			vb_sync(vb, wb, lane);
+			sd_vb_sync(vb, wb, lane, S);
 			if (pm0 != PM_I16x16) {
 				/* coded_block_pattern, me(v) mapping of Table 9-4
 				 * (src/h264_slice_data.c:1041-1080); cbp_map lane =
@@ -2011,7 +2067,7 @@ sd_slice_data(WaveBits &wb, const VlcTabs &vt, uint32_t cbp_map, uint32_t lane,
 				uint32_t serr = 0;
 				SD_T(9);
 				while (todo) {
-					vb_sync(vb, wb, lane);
+					sd_vb_sync(vb, wb, lane, S);
 					vb_norm(vb, wb);
 					/* Runs of empty blocks.  For nC < 8 the code word
 					 * for "no coefficient" is a string of 1, 2 or 4
@@ -2146,6 +2202,10 @@ struct sd_args {
 	/* LDS of one wave: SD_STAGE_OFF + max(SD_STAGE_BYTES, SD_REC_BYTES +
 	 * (16 or 32) * row_pitch) */
 	uint32_t wave_lds_bytes;
+	/* workgroups per dispatch layer (the number of compute units): the
+	 * age rank of a wave on its SIMD is blockIdx.x / prio_div; 0: the launch
+	 * fits one layer, no priority rotation */
+	uint32_t prio_div;
 };
 
 template <bool WITH_MBAFF>
@@ -2180,6 +2240,12 @@ __device__ __forceinline__ void sd_kernel_body(const sd_args &a)
 	S.pcm_chroma = 0;
 	S.t8x8_mode = S.direct8x8 = S.entropy = S.unsupported = 0;
 	S.mbaff = 0;
+	/* a launch of one workgroup per compute unit or less has every wave
+	 * alone on its SIMD: nothing to share (and stepping through the low
+	 * priorities there costs 2 %: the scalar unit and LDS are shared with
+	 * the other SIMDs' waves) */
+	S.prio_slot = a.prio_div ? (blockIdx.x / a.prio_div) & 3u : 0u;
+	S.prio_on = a.prio_div ? 1u : 0u;
 	S.fmo = S.fmo_type = S.pps_version = S.frame_mbs_only = 0;
 	S.map_units_h = S.change_cycle = 0;
 	S.change_rate = 1;
@@ -2194,6 +2260,7 @@ __device__ __forceinline__ void sd_kernel_body(const sd_args &a)
 #ifdef SD_PHASE_TIMERS
 	SdTimers T;
 	T.acc = T.cnt = T.last = 0;
+	T.t0 = T.r0 = 0;
 #endif
 	OutCtx o;
 	o.tier = a.tier;
@@ -2297,6 +2364,8 @@ __device__ __forceinline__ void sd_kernel_body(const sd_args &a)
 					uint32_t cbp_map = a.vlc->cbp[lane];
 #ifdef SD_PHASE_TIMERS
 					T.last = (uint32_t)__builtin_readcyclecounter();
+					T.t0 = __builtin_readcyclecounter();
+					T.r0 = __builtin_amdgcn_s_memrealtime();
 #endif
 					if (S.mbaff) {
 						/* the engine launches the pair-aware
@@ -2340,6 +2409,13 @@ __device__ __forceinline__ void sd_kernel_body(const sd_args &a)
 			*reinterpret_cast<uint32_t *>(o.mb_out + (size_t)lane * o.mb_stride) = T.acc;
 			*reinterpret_cast<uint32_t *>(o.mb_out + (size_t)(16u + lane) * o.mb_stride) = T.cnt;
 		}
+		/* words 32 / 33: the wave's shader-clock ticks and 100 MHz ticks
+		 * over the slice data: the clock it really ran at */
+		uint32_t dt = (uint32_t)(__builtin_readcyclecounter() - T.t0);
+		uint32_t dr = (uint32_t)(__builtin_amdgcn_s_memrealtime() - T.r0);
+		if (lane < 3u)
+			*reinterpret_cast<uint32_t *>(o.mb_out + (size_t)(32u + lane) * o.mb_stride) =
+				lane == 0 ? dt : lane == 1 ? dr : (uint32_t)T.r0;
 	}
 #endif
 

@@ -62,16 +62,44 @@ def main():
     acc = np.zeros(16)
     cnt = np.zeros(16)
     take = min(n, 64)
+    mhz = []
+    wall = []
     for i in range(take):
-        w = eng.fetch_mb(out, i, 32).reshape(-1).view(np.uint32)[:32]
-        if i == 0:
-            print('raw', w.tolist(), file=sys.stderr)
+        w = eng.fetch_mb(out, i, 34).reshape(-1).view(np.uint32)[:34]
+        if w[33]:
+            mhz.append(100.0 * float(w[32]) / float(w[33]))
+            wall.append(float(w[33]) / 1e5)
         acc += w[:16]
-        cnt += w[16:]
+        cnt += w[16:32]
+    # when did the waves start?  (word 34: 100 MHz tick at the start of the
+    # slice data; a sample over the whole batch)
+    starts, walls = [], []
+    for i in range(0, n, max(1, n // 512)):
+        w = eng.fetch_mb(out, i, 35).reshape(-1).view(np.uint32)[:35]
+        starts.append(int(w[34]))
+        walls.append((float(w[33]) / 1e5, i))
+    ws = sorted(walls)
+    print("own wall time over the slice data, sample of %d waves: min %.2f "
+          "median %.2f 90 %% %.2f max %.2f ms (slice %d)" %
+          (len(ws), ws[0][0], ws[len(ws) // 2][0], ws[int(len(ws) * 0.9)][0],
+           ws[-1][0], ws[-1][1]))
+    by_q = [np.mean([w for w, i in walls if i * 4 // n == q]) for q in range(4)]
+    print("mean by quarter of the batch: " + " ".join("%.2f" % x for x in by_q))
+    s0 = min(starts)
+    late = sorted((x - s0) / 1e5 for x in starts)
+    print("start of the slice data after the first wave's, ms: median %.2f, "
+          "90 %% %.2f, max %.2f" % (late[len(late) // 2],
+                                  late[int(len(late) * 0.9)], late[-1]))
     mbs = 8160.0 * take
     mark = acc[15] / max(cnt[15], 1)
     print("kernel %.2f ms, %d slices; a mark costs %.1f cycles" %
           (ms, n, mark))
+    if mhz:
+        print("shader clock over the slice data (s_memtime ticks per 100 MHz "
+              "tick of s_memrealtime): %.0f MHz (min %.0f, max %.0f)" %
+              (np.mean(mhz), min(mhz), max(mhz)))
+        print("a wave's own wall time over its slice data: mean %.2f ms, "
+              "max %.2f ms" % (np.mean(wall), max(wall)))
     total = 0.0
     rows = []
     for k in range(15):
