@@ -790,6 +790,7 @@ extern "C" int h264_amd_decode_slices(struct h264_amd_engine *e,
 		c.headers = a.headers;
 		c.mb_out = a.mb_out;
 		c.row_pitch = a.row_pitch;
+		c.prio_div = c.n > 4u * e->cu_count ? 4u * e->cu_count : 0u;
 		size_t clds = CB_ROW_OFF + (((size_t)c.row_pitch + 15u) & ~(size_t)15u);
 		if (clds > 160u * 1024u)
 			return -E2BIG;

@@ -58,6 +58,10 @@ struct cb_args {
 	const struct h264_slice_header *headers;
 	uint8_t *mb_out;
 	uint32_t row_pitch; /* macroblock columns of neighbour context in LDS */
+	/* waves per dispatch layer (4 per compute unit; one-wave workgroups):
+	 * blockIdx.x / prio_div is a wave's age rank on its SIMD; 0: the launch
+	 * fits one layer, no priority rotation (see slice_decode.hip) */
+	uint32_t prio_div;
 };
 
 struct BacDec {
@@ -140,7 +144,8 @@ __device__ __forceinline__ int
 cb_slice_data(WaveBits &wb, const BacTabs &bt, uint16_t *ctx, uint8_t *stage,
 	      uint8_t *row, OutCtx &o, uint32_t lane, uint32_t type, uint32_t cat,
 	      uint32_t W, uint32_t first_mb, uint32_t field_pic,
-	      uint32_t mb_capacity, uint32_t &mb_count)
+	      uint32_t mb_capacity, uint32_t &mb_count, uint32_t prio_slot,
+	      uint32_t prio_mask)
 {
 	BacDec d;
 	d.eof = 0;
@@ -173,6 +178,25 @@ cb_slice_data(WaveBits &wb, const BacTabs &bt, uint16_t *ctx, uint8_t *stage,
 	for (;;) {
 		if (mbidx >= mb_capacity)
 			return H264_AMD_E_MB_OVERFLOW;
+		/* fair shares of the SIMD (the arbiter serves the oldest wave
+		 * first, see the slice-data loop of slice_decode.hip): a step
+		 * round the four priorities every 256 macroblocks */
+		if ((mbidx & prio_mask) == 0u) {
+			switch (((mbidx >> 8) + prio_slot) & 3u) {
+			case 0:
+				__builtin_amdgcn_s_setprio(0);
+				break;
+			case 1:
+				__builtin_amdgcn_s_setprio(1);
+				break;
+			case 2:
+				__builtin_amdgcn_s_setprio(2);
+				break;
+			default:
+				__builtin_amdgcn_s_setprio(3);
+				break;
+			}
+		}
 		/* neighbours inside the slice (ref src/h264_macroblock.c:306-351) */
 		const uint32_t nbA = (mbx != 0 && mbidx >= 1) ? left : 0u;
 		const uint32_t nbB = mbidx >= W ? wb_uniform(row[mbx]) : 0u;
@@ -387,7 +411,9 @@ h264_amd_k_decode_cabac_subset(cb_args a)
 		}
 		status = cb_slice_data(wb, bt, ctx, stage, row, o, lane, type,
 				       r.chroma_array_type, W, r.first_mb_in_slice,
-				       field_pic, a.mb_capacity, mb_count);
+				       field_pic, a.mb_capacity, mb_count,
+				       a.prio_div ? (blockIdx.x / a.prio_div) & 3u : 0u,
+				       a.prio_div ? 255u : 0xffffffffu);
 	}
 
 	/* T0: flush the partial last group of 64 words */
