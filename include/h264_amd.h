@@ -314,15 +314,26 @@ H264_API int h264_amd_gather_nal_heads(struct h264_amd_engine *eng,
 
 /* ---- slice decode -------------------------------------------------------- */
 /* reader_flags bit beside H264_READER_FLAGS_SLICE_DATA: also walk the slice
- * data of CABAC slices as far as the CABAC SUBSET goes.  The reference has no
- * CABAC decoder (it returns before CABAC slice data,
- * src/h264_syntax_slice_data.h:715-717), so this is an extension and off by
- * default; the drop-in library never sets it.  The subset is what the
- * reference's own writers emit: mb_skip_flag = 1 macroblocks in P/SP/B slices,
- * I_16x16 macroblocks without residual in I slices, end_of_slice_flag.  A
- * slice leaving the subset ends with H264_AMD_E_UNSUPPORTED after the
- * macroblocks decoded so far.  Needs d_headers. */
-#define H264_AMD_READER_FLAGS_CABAC_SUBSET 0x100u
+ * data of CABAC slices.  The reference has no CABAC decoder (it returns before
+ * CABAC slice data, src/h264_syntax_slice_data.h:715-717), so this is an
+ * extension and off by default; the drop-in library never sets it.  The
+ * decoder follows the standard (9.3: binarisations, context index rules,
+ * arithmetic decoding engine) for I / SI / P / SP / B slices of frame and field
+ * pictures, all chroma formats, 8x8 transform, I_PCM -- spec-only and therefore
+ * "parity unpinned", except for what the reference's own writers emit
+ * (h264_write_grey_i_slice / h264_write_skipped_p_slice), which it decodes
+ * exactly.  Context variables are initialised as the REFERENCE does it
+ * (SliceQPY clipped to 1..51, src/h264_bac.c:216-230).  MBAFF frames and slice
+ * groups with CABAC end with H264_AMD_E_UNSUPPORTED.  Records are the T2
+ * records of CAVLC with these conventions: an 8x8 block's coefficient 4k + j is
+ * coefficient k of the 4x4 array j of its quadrant (the interleaving CAVLC
+ * uses, ref src/h264_syntax_slice_data.h:323-326); nz_coeff[] counts the
+ * non-zero coefficients of each 4x4 array, DC blocks not counted; a level
+ * beyond 16 bits wraps; unary codes are bounded (mb_qp_delta, ref_idx: 255;
+ * Exp-Golomb escapes: 24 prefix bits) and end the slice with -EIO beyond.
+ * Needs d_headers. */
+#define H264_AMD_READER_FLAGS_CABAC 0x100u
+#define H264_AMD_READER_FLAGS_CABAC_SUBSET H264_AMD_READER_FLAGS_CABAC /* round-2 name */
 struct h264_amd_decode_args {
 	const uint8_t *d_buf; /* NAL bytes */
 	const struct h264_amd_slice_desc *d_descs; /* [n] */

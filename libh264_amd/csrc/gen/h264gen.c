@@ -177,6 +177,8 @@ static struct code mk(const char *s)
 	return c;
 }
 
+static void cabac_tables_init(void);
+
 static void tables_init(void)
 {
 #define H264_CT(col, bits, t1, tc) s_ct[col][t1][tc] = mk(bits);
@@ -188,6 +190,7 @@ static void tables_init(void)
 	s_cbp_code[cls][0][intra] = code;                                      \
 	s_cbp_code[cls][1][inter] = code;
 #include "../common/h264_cavlc_tables.inc"
+	cabac_tables_init();
 }
 
 static void put_code(struct bw *w, struct code c)
@@ -400,6 +403,30 @@ int h264gen_sei_user_data(uint32_t n, uint64_t seed, uint8_t *out, size_t cap)
 }
 
 /* ---- slice state --------------------------------------------------------- */
+/* CABAC: the arithmetic encoder and what later macroblocks look at
+ * (h264gen_cabac.inc) */
+struct cenc {
+	struct bw *w;
+	uint32_t low, range, outstanding;
+	int first;
+	uint8_t st[1024]; /* pStateIdx | valMPS << 6 */
+	uint64_t bins;
+};
+
+struct cmb {
+	uint8_t mbt; /* MB_* */
+	uint8_t skip, pcm, intra, t8;
+	uint8_t cbp; /* luma | chroma << 4; I_PCM: 0x2f */
+	uint8_t icp; /* intra_chroma_pred_mode */
+	uint8_t dc; /* coded_block_flag of DC blocks: bit 0 Y (Intra16x16), 1 Cb, 2 Cr */
+	/* coded_block_flag per 4x4 block, bit y * w + x: [0] luma (w = 4),
+	 * [1] [2] Cb Cr -- like luma with ChromaArrayType 3, else the chroma AC
+	 * blocks (w = 2).  8x8 blocks own four bits */
+	uint16_t cbf[3];
+	uint8_t ref[2][4]; /* ref_idx as transmitted per 8x8 block, y * 2 + x */
+	uint16_t amvd[2][16][2]; /* |mvd| as transmitted per 4x4 block, y * 4 + x */
+};
+
 struct gen {
 	const struct h264gen_cfg *c;
 	const struct h264gen_slice *s;
@@ -420,6 +447,11 @@ struct gen {
 	/* MBAFF frame (field_coding 2, frame picture): macroblock pairs */
 	int mbaff;
 	uint8_t *ff; /* [num_mbs] mb_field_decoding_flag as finally inferred */
+	/* CABAC (entropy_coding_mode_flag with cabac_syntax) */
+	int cabac;
+	struct cenc ce;
+	struct cmb *ci; /* [num_mbs] */
+	uint32_t prev_qpd_nz; /* previous macroblock carried mb_qp_delta != 0 */
 };
 
 /* ---- slice groups (8.2.2), written from the standard ------------------------- */
@@ -993,6 +1025,8 @@ static int32_t pick_qpd(struct gen *g)
 	return rng_below(&g->r, 4) == 0 ? (int32_t)rng_below(&g->r, 13) - 6 : 0;
 }
 
+#include "h264gen_cabac.inc"
+
 /* intra macroblock; `base` is the mb_type offset of the slice type */
 static void put_intra_mb(struct gen *g, uint32_t i, uint32_t base, uint8_t *rec)
 {
@@ -1004,7 +1038,21 @@ static void put_intra_mb(struct gen *g, uint32_t i, uint32_t base, uint8_t *rec)
 		uint32_t nch = g->cat == 0 ? 0 : g->cat == 1 ? 64 : g->cat == 2 ? 128 : 256;
 		int zero = rng_pm(&g->r, g->s->pm_zero_pcm);
 		uint16_t *pc = rec ? (uint16_t *)coef_of(rec) : NULL;
-		bw_ue(w, base + 25);
+		if (g->cabac) {
+			/* mb_type ends in a terminating bin that flushes the
+			 * arithmetic encoder; it restarts behind the samples
+			 * (9.3.1.2), the context variables carry on */
+			g->ci[i].mbt = MB_I_PCM;
+			g->ci[i].intra = 1;
+			c_mb_type(g, i, base + 25, base != 0 && !g->si);
+			g->ci[i].pcm = 1;
+			g->ci[i].cbp = 0x2f;
+			g->ci[i].dc = 7;
+			g->ci[i].cbf[0] = g->ci[i].cbf[1] = g->ci[i].cbf[2] = 0xffff;
+			g->prev_qpd_nz = 0;
+		} else {
+			bw_ue(w, base + 25);
+		}
 		while (w->nbits != 0)
 			bw_u(w, 0, 1);
 		for (k = 0; k < 256 + 2 * nch; k++) {
@@ -1015,6 +1063,8 @@ static void put_intra_mb(struct gen *g, uint32_t i, uint32_t base, uint8_t *rec)
 			if (pc)
 				pc[k] = (uint16_t)v;
 		}
+		if (g->cabac)
+			ce_start(&g->ce);
 		memset(g->nz + (size_t)i * 48, 16, 48);
 		rec_head(rec, MB_I_PCM, 0, 0, base + 25, 0);
 		return;
@@ -1026,18 +1076,36 @@ static void put_intra_mb(struct gen *g, uint32_t i, uint32_t base, uint8_t *rec)
 		uint32_t t = 1 + pred + 4 * chroma + (luma ? 12 : 0);
 		uint32_t icp = 0;
 		int32_t qpd = pick_qpd(g);
-		bw_ue(w, base + t);
+		if (g->cabac) {
+			g->ci[i].mbt = MB_I_16x16;
+			g->ci[i].intra = 1;
+			c_mb_type(g, i, base + t, base != 0 && !g->si);
+		} else {
+			bw_ue(w, base + t);
+		}
 		if (g->cat == 1 || g->cat == 2) {
 			icp = rng_below(&g->r, 4);
-			bw_ue(w, icp);
+			if (g->cabac)
+				c_icp(g, i, icp);
+			else
+				bw_ue(w, icp);
 		}
-		bw_se(w, qpd);
+		if (g->cabac)
+			c_qpd(g, qpd);
+		else
+			bw_se(w, qpd);
 		rec_head(rec, MB_I_16x16, luma | (chroma << 4), 0, base + t, qpd);
 		if (rec) {
 			rec[6] = (uint8_t)icp;
 			rec[7] = (uint8_t)pred;
 		}
-		put_residual(g, i, 1, luma, chroma, rec);
+		if (g->cabac) {
+			g->ci[i].cbp = (uint8_t)(luma | (chroma << 4));
+			c_residual(g, i, 1, luma, chroma, 0, rec);
+			c_count_nz(g, i, 1, rec);
+		} else {
+			put_residual(g, i, 1, luma, chroma, rec);
+		}
 		return;
 	}
 	/* I_NxN, or the SI macroblock (mb_type 0) of an SI slice: Intra_4x4
@@ -1051,59 +1119,138 @@ static void put_intra_mb(struct gen *g, uint32_t i, uint32_t base, uint8_t *rec)
 		uint32_t luma, chroma, cbp, icp = 0;
 		int32_t qpd = 0;
 		int no_res = rng_pm(&g->r, g->s->pm_cbp_zero);
-		bw_ue(w, si_mb ? 0 : base + 0);
-		if (!si_mb && g->c->transform_8x8_mode_flag)
-			bw_u(w, (uint32_t)t8, 1);
+		if (g->cabac) {
+			c_mb_type(g, i, si_mb ? 0 : base + 0, base != 0 && !g->si);
+			g->ci[i].mbt = si_mb ? MB_SI : MB_I_NxN;
+			g->ci[i].intra = 1;
+		} else {
+			bw_ue(w, si_mb ? 0 : base + 0);
+		}
+		if (!si_mb && g->c->transform_8x8_mode_flag) {
+			if (g->cabac)
+				c_t8(g, i, (uint32_t)t8);
+			else
+				bw_u(w, (uint32_t)t8, 1);
+		}
 		n = t8 ? 4 : 16;
 		for (b = 0; b < n; b++) {
 			if (rng_below(&g->r, 2)) {
-				bw_u(w, 1, 1);
+				if (g->cabac)
+					c_ipred(g, 1, 0);
+				else
+					bw_u(w, 1, 1);
 			} else {
 				uint32_t m = rng_below(&g->r, 8);
-				bw_u(w, 0, 1);
-				bw_u(w, m, 3);
+				if (g->cabac) {
+					c_ipred(g, 0, m);
+				} else {
+					bw_u(w, 0, 1);
+					bw_u(w, m, 3);
+				}
 				if (rec)
 					rec[8 + b / 2] |= (uint8_t)((m + 1) << (4 * (b & 1)));
 			}
 		}
 		if (g->cat == 1 || g->cat == 2) {
 			icp = rng_below(&g->r, 4);
-			bw_ue(w, icp);
+			if (g->cabac)
+				c_icp(g, i, icp);
+			else
+				bw_ue(w, icp);
 		}
 		luma = no_res ? 0 : rng_below(&g->r, 16);
 		chroma = (no_res || !(g->cat == 1 || g->cat == 2)) ? 0 : rng_below(&g->r, 3);
 		cbp = luma | (chroma << 4);
-		bw_ue(w, s_cbp_code[(g->cat == 1 || g->cat == 2) ? 0 : 1][0][cbp]);
+		if (g->cabac)
+			c_cbp(g, i, cbp);
+		else
+			bw_ue(w, s_cbp_code[(g->cat == 1 || g->cat == 2) ? 0 : 1][0][cbp]);
 		if (si_mb && luma > 0 && g->c->transform_8x8_mode_flag) {
 			t8 = rng_pm(&g->r, g->s->pm_t8x8);
-			bw_u(w, (uint32_t)t8, 1);
+			if (g->cabac)
+				c_t8(g, i, (uint32_t)t8);
+			else
+				bw_u(w, (uint32_t)t8, 1);
 		}
 		if (cbp) {
 			qpd = pick_qpd(g);
-			bw_se(w, qpd);
+			if (g->cabac)
+				c_qpd(g, qpd);
+			else
+				bw_se(w, qpd);
+		} else if (g->cabac) {
+			g->prev_qpd_nz = 0;
 		}
 		rec_head(rec, si_mb ? MB_SI : MB_I_NxN, cbp, t8 ? MBF_T8X8 : 0,
 			 si_mb ? 0 : base + 0, qpd);
 		if (rec)
 			rec[6] = (uint8_t)icp;
-		if (cbp)
+		if (g->cabac) {
+			g->ci[i].cbp = (uint8_t)cbp;
+			if (cbp)
+				c_residual(g, i, 0, luma, chroma, t8, rec);
+			c_count_nz(g, i, 0, rec);
+		} else if (cbp) {
 			put_residual(g, i, 0, luma, chroma, rec);
+		}
 	}
 }
 
-static void put_mvd(struct gen *g, int16_t *dst)
+/* where a (sub-)macroblock partition lies: x4 | y4 << 4 | w4 << 8 | h4 << 12,
+ * in units of 4x4 blocks (6.4.2) */
+static uint32_t part_geom(uint32_t mbt, uint32_t p)
+{
+	if (mbt == MB_P_16x8 || mbt == MB_B_16x8)
+		return 0u | (2u * p) << 4 | 4u << 8 | 2u << 12;
+	if (mbt == MB_P_8x16 || mbt == MB_B_8x16)
+		return 2u * p | 0u << 4 | 2u << 8 | 4u << 12;
+	return 0u | 0u << 4 | 4u << 8 | 4u << 12; /* 16x16 */
+}
+#define PART_X8(mbt, p) ((part_geom(mbt, p) & 15u) / 2u)
+#define PART_Y8(mbt, p) (((part_geom(mbt, p) >> 4) & 15u) / 2u)
+#define PART_W8(mbt) (((part_geom(mbt, 0) >> 8) & 15u) / 2u)
+#define PART_H8(mbt) (((part_geom(mbt, 0) >> 12) & 15u) / 2u)
+
+static uint32_t sub_geom(int isb, uint32_t sub, uint32_t p, uint32_t s)
+{
+	/* shape of the sub-macroblock partitions: 0 8x8, 1 8x4, 2 4x8, 3 4x4 */
+	static const uint8_t bshape[13] = {3, 0, 0, 0, 1, 2, 1, 2, 1, 2, 3, 3, 3};
+	uint32_t shape = isb ? bshape[sub] : sub;
+	uint32_t x = 2u * (p & 1u), y = 2u * (p >> 1), w = 2, h = 2;
+	if (shape == 1) {
+		h = 1;
+		y += s;
+	} else if (shape == 2) {
+		w = 1;
+		x += s;
+	} else if (shape == 3) {
+		w = h = 1;
+		x += s & 1u;
+		y += s >> 1;
+	}
+	return x | y << 4 | w << 8 | h << 12;
+}
+
+static void put_mvd(struct gen *g, uint32_t i, uint32_t list, uint32_t geom,
+		    int16_t *dst)
 {
 	uint32_t c;
+	int32_t mv[2];
 	for (c = 0; c < 2; c++) {
 		int32_t v = rng_below(&g->r, 3) == 0
 				    ? 0
 				    : (int32_t)rng_below(&g->r, 65) - 32;
 		if (rng_below(&g->r, 64) == 0)
 			v = (int32_t)rng_below(&g->r, 4001) - 2000;
-		bw_se(&g->w, v);
+		if (!g->cabac)
+			bw_se(&g->w, v);
+		mv[c] = v;
 		if (dst)
 			dst[c] = (int16_t)v;
 	}
+	if (g->cabac)
+		c_mvd(g, i, list, geom & 15u, (geom >> 4) & 15u, (geom >> 8) & 15u,
+		      geom >> 12, mv);
 }
 
 /* inter macroblock of a P or B slice (7.3.5.1, 7.3.5.2) */
@@ -1132,7 +1279,8 @@ static void put_inter_mb(struct gen *g, uint32_t i, uint8_t *rec)
 	static const uint8_t psub_n[4] = {1, 2, 2, 4};
 
 	if (!isb) {
-		t = rng_below(&g->r, 5);
+		/* P_8x8ref0 has no CABAC bin string (Table 9-37) */
+		t = rng_below(&g->r, g->cabac ? 4 : 5);
 		nparts = t == 0 ? 1 : t <= 2 ? 2 : 4;
 		mbt = MB_P_16x16 + t;
 		for (p = 0; p < nparts; p++)
@@ -1157,12 +1305,20 @@ static void put_inter_mb(struct gen *g, uint32_t i, uint8_t *rec)
 			mbt = MB_B_8x8;
 		}
 	}
-	bw_ue(w, t);
+	if (g->cabac) {
+		g->ci[i].mbt = (uint8_t)mbt;
+		c_mb_type(g, i, t, 0);
+	} else {
+		bw_ue(w, t);
+	}
 
 	if (nparts == 4) {
 		for (p = 0; p < 4; p++) {
 			sub[p] = rng_below(&g->r, isb ? 13 : 4);
-			bw_ue(w, sub[p]);
+			if (g->cabac)
+				c_sub_mb_type(g, sub[p]);
+			else
+				bw_ue(w, sub[p]);
 			if (isb) {
 				pm[p] = bsub_pm[sub[p]];
 				nsub[p] = bsub_n[sub[p]];
@@ -1184,7 +1340,10 @@ static void put_inter_mb(struct gen *g, uint32_t i, uint8_t *rec)
 				if (pm[p] != PM_DIRECT && pm[p] != PM_L1) {
 					uint32_t v = rng_below(
 						&g->r, ref_range(g, i, g->nref0) + 1);
-					bw_te(w, v, ref_range(g, i, g->nref0));
+					if (g->cabac)
+						c_ref_idx(g, i, 0, p & 1u, p >> 1, 1, 1, v);
+					else
+						bw_te(w, v, ref_range(g, i, g->nref0));
 					if (rec)
 						rec[64 + p] = (uint8_t)v;
 				}
@@ -1194,7 +1353,10 @@ static void put_inter_mb(struct gen *g, uint32_t i, uint8_t *rec)
 				if (pm[p] != PM_DIRECT && pm[p] != PM_L0) {
 					uint32_t v = rng_below(
 						&g->r, ref_range(g, i, g->nref1) + 1);
-					bw_te(w, v, ref_range(g, i, g->nref1));
+					if (g->cabac)
+						c_ref_idx(g, i, 1, p & 1u, p >> 1, 1, 1, v);
+					else
+						bw_te(w, v, ref_range(g, i, g->nref1));
 					if (rec)
 						rec[68 + p] = (uint8_t)v;
 				}
@@ -1202,18 +1364,25 @@ static void put_inter_mb(struct gen *g, uint32_t i, uint8_t *rec)
 		for (p = 0; p < 4; p++)
 			if (pm[p] != PM_DIRECT && pm[p] != PM_L1)
 				for (s = 0; s < nsub[p]; s++)
-					put_mvd(g, mv0 ? mv0 + 8 * p + 2 * s : NULL);
+					put_mvd(g, i, 0, sub_geom(isb, sub[p], p, s),
+						mv0 ? mv0 + 8 * p + 2 * s : NULL);
 		for (p = 0; p < 4; p++)
 			if (pm[p] != PM_DIRECT && pm[p] != PM_L0)
 				for (s = 0; s < nsub[p]; s++)
-					put_mvd(g, mv1 ? mv1 + 8 * p + 2 * s : NULL);
+					put_mvd(g, i, 1, sub_geom(isb, sub[p], p, s),
+						mv1 ? mv1 + 8 * p + 2 * s : NULL);
 	} else if (pm[0] != PM_DIRECT) {
 		if (ref_present(g, i, g->nref0))
 			for (p = 0; p < nparts; p++)
 				if (pm[p] != PM_L1) {
 					uint32_t v = rng_below(
 						&g->r, ref_range(g, i, g->nref0) + 1);
-					bw_te(w, v, ref_range(g, i, g->nref0));
+					if (g->cabac)
+						c_ref_idx(g, i, 0, PART_X8(mbt, p),
+							  PART_Y8(mbt, p), PART_W8(mbt),
+							  PART_H8(mbt), v);
+					else
+						bw_te(w, v, ref_range(g, i, g->nref0));
 					if (rec)
 						rec[64 + p] = (uint8_t)v;
 				}
@@ -1222,16 +1391,21 @@ static void put_inter_mb(struct gen *g, uint32_t i, uint8_t *rec)
 				if (pm[p] != PM_L0) {
 					uint32_t v = rng_below(
 						&g->r, ref_range(g, i, g->nref1) + 1);
-					bw_te(w, v, ref_range(g, i, g->nref1));
+					if (g->cabac)
+						c_ref_idx(g, i, 1, PART_X8(mbt, p),
+							  PART_Y8(mbt, p), PART_W8(mbt),
+							  PART_H8(mbt), v);
+					else
+						bw_te(w, v, ref_range(g, i, g->nref1));
 					if (rec)
 						rec[68 + p] = (uint8_t)v;
 				}
 		for (p = 0; p < nparts; p++)
 			if (pm[p] != PM_L1)
-				put_mvd(g, mv0 ? mv0 + 8 * p : NULL);
+				put_mvd(g, i, 0, part_geom(mbt, p), mv0 ? mv0 + 8 * p : NULL);
 		for (p = 0; p < nparts; p++)
 			if (pm[p] != PM_L0)
-				put_mvd(g, mv1 ? mv1 + 8 * p : NULL);
+				put_mvd(g, i, 1, part_geom(mbt, p), mv1 ? mv1 + 8 * p : NULL);
 	}
 
 	if (rng_pm(&g->r, g->s->pm_cbp_zero)) {
@@ -1241,19 +1415,36 @@ static void put_inter_mb(struct gen *g, uint32_t i, uint8_t *rec)
 		chroma = (g->cat == 1 || g->cat == 2) ? rng_below(&g->r, 3) : 0;
 	}
 	cbp = luma | (chroma << 4);
-	bw_ue(w, s_cbp_code[(g->cat == 1 || g->cat == 2) ? 0 : 1][1][cbp]);
+	if (g->cabac)
+		c_cbp(g, i, cbp);
+	else
+		bw_ue(w, s_cbp_code[(g->cat == 1 || g->cat == 2) ? 0 : 1][1][cbp]);
 	if (luma > 0 && g->c->transform_8x8_mode_flag && no_sub8 &&
 	    (mbt != MB_B_Direct_16x16 || g->c->direct_8x8_inference_flag)) {
 		t8 = rng_pm(&g->r, g->s->pm_t8x8);
-		bw_u(w, (uint32_t)t8, 1);
+		if (g->cabac)
+			c_t8(g, i, (uint32_t)t8);
+		else
+			bw_u(w, (uint32_t)t8, 1);
 	}
 	if (cbp) {
 		qpd = pick_qpd(g);
-		bw_se(w, qpd);
+		if (g->cabac)
+			c_qpd(g, qpd);
+		else
+			bw_se(w, qpd);
+	} else if (g->cabac) {
+		g->prev_qpd_nz = 0;
 	}
 	rec_head(rec, mbt, cbp, t8 ? MBF_T8X8 : 0, t, qpd);
-	if (cbp)
+	if (g->cabac) {
+		g->ci[i].cbp = (uint8_t)cbp;
+		if (cbp)
+			c_residual(g, i, 0, luma, chroma, t8, rec);
+		c_count_nz(g, i, 0, rec);
+	} else if (cbp) {
 		put_residual(g, i, 0, luma, chroma, rec);
+	}
 }
 
 /* ---- slice header (7.3.3) ------------------------------------------------ */
@@ -1440,7 +1631,7 @@ int h264gen_slice_nal(const struct h264gen_cfg *cfg,
 	bw_init(&g.w, out, cap);
 	put_slice_header(&g);
 
-	if (cfg->entropy_coding_mode_flag) {
+	if (cfg->entropy_coding_mode_flag && !sl->cabac_syntax) {
 		/* opaque CABAC payload: the reader only records its extent */
 		while (g.w.nbits != 0)
 			bw_u(&g.w, 1, 1);
@@ -1453,12 +1644,27 @@ int h264gen_slice_nal(const struct h264gen_cfg *cfg,
 	g.mbaff = cfg->field_coding == 2 && !sl->field_pic;
 	if (g.mbaff && (sl->num_mbs & 1u))
 		return -EINVAL; /* whole macroblock pairs */
+	g.cabac = cfg->entropy_coding_mode_flag != 0;
+	if (g.cabac && g.mbaff)
+		return -EINVAL; /* no CABAC generator for MBAFF frames */
 	g.nz = calloc((size_t)sl->num_mbs, 48);
 	g.ff = calloc((size_t)sl->num_mbs, 1);
-	if (g.nz == NULL || g.ff == NULL) {
+	if (g.cabac)
+		g.ci = calloc((size_t)sl->num_mbs, sizeof(*g.ci));
+	if (g.nz == NULL || g.ff == NULL || (g.cabac && g.ci == NULL)) {
 		free(g.nz);
 		free(g.ff);
+		free(g.ci);
 		return -ENOMEM;
+	}
+	if (g.cabac) {
+		/* cabac_alignment_one_bit, then the arithmetic code (7.3.4) */
+		while (g.w.nbits != 0)
+			bw_u(&g.w, 1, 1);
+		g.ce.w = &g.w;
+		ce_start(&g.ce);
+		ce_init_states(&g.ce, g.st == 2, sl->cabac_init_idc,
+			       26 + cfg->pic_init_qp_minus26 + sl->slice_qp_delta);
 	}
 	if (cfg->num_slice_groups_minus1 > 0) {
 		/* the slice codes macroblocks of first_mb's group, in address
@@ -1482,6 +1688,7 @@ int h264gen_slice_nal(const struct h264gen_cfg *cfg,
 			free(g.idx_of);
 			free(g.nz);
 			free(g.ff);
+			free(g.ci);
 			return nm < 0 ? (int)nm : -EINVAL;
 		}
 		for (a = 0; a < total; a++)
@@ -1499,6 +1706,7 @@ int h264gen_slice_nal(const struct h264gen_cfg *cfg,
 			free(g.idx_of);
 			free(g.nz);
 			free(g.ff);
+			free(g.ci);
 			return -ERANGE;
 		}
 		g.n_addr = total;
@@ -1522,6 +1730,8 @@ int h264gen_slice_nal(const struct h264gen_cfg *cfg,
 			put_intra_mb(&g, i, g.si ? 1 : 0, rec);
 			if (rec)
 				memcpy(rec + 16, g.nz + (size_t)i * 48, 48);
+			if (g.cabac) /* end_of_slice_flag */
+				ce_term(&g.ce, i + 1 == sl->num_mbs);
 			continue;
 		}
 		/* P / B */
@@ -1530,6 +1740,26 @@ int h264gen_slice_nal(const struct h264gen_cfg *cfg,
 			int skip = rng_pm(&g.r, sl->pm_skip);
 			if (last)
 				skip = sl->end_with_skip ? 1 : 0;
+			if (g.cabac) {
+				/* mb_skip_flag per macroblock instead of runs */
+				c_skip_flag(&g, i, (uint32_t)skip);
+				if (skip) {
+					g.ci[i].skip = 1;
+					g.ci[i].mbt = g.st == 1 ? MB_B_SKIP : MB_P_SKIP;
+					g.prev_qpd_nz = 0;
+					rec_head(rec, g.st == 1 ? MB_B_SKIP : MB_P_SKIP,
+						 0, MBF_SKIPPED, 0, 0);
+				} else {
+					if (rng_pm(&g.r, sl->pm_intra_in_inter))
+						put_intra_mb(&g, i, g.st == 1 ? 23 : 5, rec);
+					else
+						put_inter_mb(&g, i, rec);
+					if (rec)
+						memcpy(rec + 16, g.nz + (size_t)i * 48, 48);
+				}
+				ce_term(&g.ce, (uint32_t)last);
+				continue;
+			}
 			if (skip) {
 				run++;
 				if (g.mbaff) {
@@ -1589,9 +1819,16 @@ int h264gen_slice_nal(const struct h264gen_cfg *cfg,
 				memcpy(rec + 16, g.nz + (size_t)i * 48, 48);
 		}
 	}
-	bw_trailing(&g.w);
+	if (g.cabac) {
+		/* the encoder's flush wrote the stop bit (9.3.4.5) */
+		while (g.w.nbits != 0)
+			bw_u(&g.w, 0, 1);
+	} else {
+		bw_trailing(&g.w);
+	}
 	free(g.nz);
 	free(g.ff);
+	free(g.ci);
 	free(g.addr_of);
 	free(g.idx_of);
 	return finish(&g.w);

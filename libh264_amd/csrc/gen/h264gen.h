@@ -87,7 +87,10 @@ struct h264gen_slice {
 	uint32_t cabac_payload; /* CABAC PPS: bytes of opaque slice data */
 	uint32_t field_pic; /* field_coding != 0: 0 frame picture, 1 top, 2 bottom field */
 	uint32_t slice_group_change_cycle; /* slice group map types 3..5 */
-	uint32_t reserved0;
+	/* CABAC PPS: 1 = real macroblock syntax through the generator's own
+	 * arithmetic encoder (h264gen_cabac.inc; frame and field pictures, no
+	 * MBAFF); 0 = cabac_payload bytes of opaque slice data */
+	uint32_t cabac_syntax;
 	uint64_t seed;
 };
 

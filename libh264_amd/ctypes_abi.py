@@ -354,7 +354,7 @@ class GenSlice(S):
             "hdr_extras pm_i16x16 pm_pcm pm_skip pm_intra_in_inter pm_t8x8 "
             "pm_escape pm_zero_pcm density pm_cbp_zero end_with_skip "
             "cabac_payload field_pic slice_group_change_cycle "
-            "reserved0").split()] +
+            "cabac_syntax").split()] +
         [("seed", u64)])
 
 

@@ -97,6 +97,18 @@ struct orc_mb_info {
 	uint8_t skipped;
 	uint8_t field_flag;
 	uint8_t nz_coeff[48];
+	/* ---- CABAC decoding only (engine extension, orc_cabac_dec.c): what the
+	 * context index rules of 9.3.3.1.1 ask of a neighbouring macroblock ---- */
+	uint8_t mbt; /* enum h264_mb_type, not truncated */
+	uint8_t cbp; /* coded_block_pattern; I_PCM: 0x2f */
+	uint8_t t8; /* transform_size_8x8_flag */
+	uint8_t cbf_dc; /* coded_block_flag of DC blocks: bit 0 Y, 1 Cb, 2 Cr */
+	/* coded_block_flag per block: [0] by luma4x4BlkIdx, [1] [2] Cb / Cr by
+	 * cb4x4BlkIdx (ChromaArrayType 3) or chroma4x4BlkIdx; an 8x8 block sets
+	 * the four bits of its 4x4 blocks */
+	uint16_t cbf[3];
+	uint8_t ref_idx[2][4]; /* as transmitted, per 8x8 block */
+	int16_t mvd[2][16][2]; /* as transmitted, per luma4x4BlkIdx */
 };
 
 /* current macroblock (ref struct h264_macroblock, :105-167) */
@@ -309,6 +321,19 @@ int orc_avcc_to_byte_stream(uint8_t *data, size_t len);
 /* ---- CAVLC slice data (orc_cavlc.c; ref src/h264_syntax_slice_data.h,
  *      src/h264_slice_data.c, src/h264_macroblock.c) ------------------ */
 int orc_read_slice_data(struct h264_bitstream *bs, struct orc_reader *rd);
+uint32_t orc_mb_off(const struct orc_ctx *ctx, uint32_t mbAddr);
+int orc_apply_mb_type(struct orc_ctx *ctx, struct orc_mb *mb, uint32_t type);
+int orc_apply_sub_mb_type(struct orc_ctx *ctx, struct orc_mb *mb, uint32_t p,
+			  uint32_t type);
+void orc_neigh_loc(const struct orc_ctx *ctx, const struct orc_mb *mb,
+		   uint32_t maxW, uint32_t maxH, int32_t xN, int32_t yN,
+		   uint32_t *addrN, uint32_t *xW, uint32_t *yW);
+void orc_neigh_luma4x4(const struct orc_ctx *ctx, const struct orc_mb *mb,
+		       uint32_t idx, uint32_t *addrA, uint32_t *idxA,
+		       uint32_t *addrB, uint32_t *idxB);
+void orc_neigh_chroma4x4(const struct orc_ctx *ctx, const struct orc_mb *mb,
+			 uint32_t idx, uint32_t *addrA, uint32_t *idxA,
+			 uint32_t *addrB, uint32_t *idxB);
 int orc_new_macroblock(struct orc_ctx *ctx, uint32_t mbAddr, int skipped,
 		       int field_flag);
 void orc_clear_macroblock_table(struct orc_ctx *ctx);
@@ -319,9 +344,10 @@ void orc_mb_to_record(const struct orc_ctx *ctx, uint8_t *rec, uint32_t stride);
  *      src/h264_cabac.c, src/h264_cabac_ctx_tables.c, src/h264_writer.c) */
 void orc_cabac_init_states(int slice_type, uint32_t cabac_init_idc,
 			   int32_t SliceQPLuma, uint8_t states[1024][2]);
-/* engine extension (no reference behaviour): CABAC decode of the syntax the
- * reference's writers emit, see orc_cabac.c */
-int orc_cabac_subset_slice_data(struct h264_bitstream *bs, struct orc_reader *rd);
+/* engine extension (no reference behaviour, spec-only, parity unpinned beyond
+ * what the reference's writers emit): CABAC slice data, orc_cabac_dec.c */
+int orc_cabac_slice_data(struct h264_bitstream *bs, struct orc_reader *rd);
+extern uint64_t orc_stat_cabac_bins; /* bins decoded (bench statistics) */
 int orc_write_grey_i_slice(struct h264_bitstream *bs, struct orc_ctx *ctx,
 			   uint32_t mb_count);
 int orc_write_skipped_p_slice(struct h264_bitstream *bs, struct orc_ctx *ctx,

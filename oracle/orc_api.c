@@ -344,7 +344,7 @@ int orc_rec_parse_nalu(struct orc_rec *r, const uint8_t *base,
 				sr.flags |= H264_AMD_SR_CABAC;
 			if ((r->flags & H264_READER_FLAGS_SLICE_DATA) &&
 			    (!cabac ||
-			     (r->flags & H264_AMD_READER_FLAGS_CABAC_SUBSET)) &&
+			     (r->flags & H264_AMD_READER_FLAGS_CABAC)) &&
 			    res != H264_AMD_E_UNSUPPORTED)
 				sr.flags |= H264_AMD_SR_DATA_PARSED;
 			sr.slice_type = ctx->slice.type;

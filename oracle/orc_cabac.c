@@ -387,223 +387,6 @@ static int write_coded_block_flag_i16dc(struct cabac *c,
 	return enc_decision(&c->enc, &c->st[ci], flag);
 }
 
-/* ======================================================================
- * CABAC slice data, DECODE direction -- an ENGINE EXTENSION, not reference
- * behaviour: the reference returns before any CABAC slice data
- * (src/h264_syntax_slice_data.h:715-717), and so do oracle and product unless
- * H264_AMD_READER_FLAGS_CABAC_SUBSET is given.  What follows is the inverse of
- * the encoder above by the standard's decoding process (9.3.1.2 initialisation,
- * 9.3.3.2.1 DecodeDecision, 9.3.3.2.2 RenormD, 9.3.3.2.3 DecodeTerminate) for
- * exactly the syntax the reference's own writers can produce:
- *   P / SP / B slices:  mb_skip_flag = 1 macroblocks
- *   I slices:           I_16x16 macroblocks without coded residual
- *                       (mb_type 1..4, any intra_chroma_pred_mode, any
- *                       mb_qp_delta, coded_block_flag(Intra16x16DCLevel) = 0)
- * and end_of_slice_flag.  Anything else ends the slice with
- * H264_AMD_E_UNSUPPORTED at the first bin that leaves the subset; macroblocks
- * decoded until then have been delivered.  ctxIdxInc follows the standard
- * (mb_qp_delta: previous macroblock's delta != 0; coded_block_flag:
- * unavailable neighbour of an intra macroblock counts as 1), which coincides
- * with the reference encoder's shortcuts on everything that encoder emits.
- * Pinned by round trip: decode(h264_write_{grey_i,skipped_p}_slice(x)) == x.
- * ====================================================================== */
-struct bac_dec {
-	struct h264_bitstream *bs;
-	uint32_t range, offset;
-};
-
-static int dec_bits(struct bac_dec *d, uint32_t n, uint32_t *v)
-{
-	return orc_bs_read_bits(d->bs, v, n) < 0 ? -EIO : 0;
-}
-
-static int dec_renorm(struct bac_dec *d)
-{
-	while (d->range < 256) {
-		uint32_t b;
-		CHK(dec_bits(d, 1, &b));
-		d->range <<= 1;
-		d->offset = (d->offset << 1) | b;
-	}
-	return 0;
-}
-
-static int dec_decision(struct bac_dec *d, struct bac_state *s, int *bin)
-{
-	uint32_t q = (d->range >> 6) & 3;
-	uint32_t r_lps = s_lps[s->idx][q];
-	d->range -= r_lps;
-	if (d->offset >= d->range) {
-		*bin = !s->mps;
-		d->offset -= d->range;
-		d->range = r_lps;
-		if (s->idx == 0)
-			s->mps = !s->mps;
-		s->idx = s_next_lps[s->idx];
-	} else {
-		*bin = s->mps;
-		s->idx = s_next_mps[s->idx];
-	}
-	return dec_renorm(d);
-}
-
-static int dec_terminate(struct bac_dec *d, int *bin)
-{
-	d->range -= 2;
-	if (d->offset >= d->range) {
-		*bin = 1;
-		return 0;
-	}
-	*bin = 0;
-	return dec_renorm(d);
-}
-
-int orc_cabac_subset_slice_data(struct h264_bitstream *bs, struct orc_reader *rd)
-{
-	struct orc_ctx *ctx = rd->ctx;
-	const struct h264_slice_header *sh = &ctx->slice.hdr;
-	const uint32_t type = ctx->slice.type;
-	const uint32_t cat = ctx->sps_derived.ChromaArrayType;
-	struct bac_state st[1024];
-	struct bac_dec d;
-	uint8_t init[1024][2];
-	uint32_t addr, mb_count = 0, i, v;
-	int prev_qp_nonzero = 0, bin;
-
-	if (ctx->derived.MbaffFrameFlag || ctx->pps->num_slice_groups_minus1 > 0)
-		return H264_AMD_E_UNSUPPORTED;
-	if (ctx->sps_derived.PicWidthInMbs == 0 ||
-	    ctx->sps_derived.PicWidthInMbs > H264_AMD_MAX_PIC_WIDTH_MBS)
-		return H264_AMD_E_UNSUPPORTED;
-	cabac_tables_init();
-	if (rd->cbs.slice_data_begin)
-		rd->cbs.slice_data_begin(ctx, sh, rd->userdata);
-	orc_clear_macroblock_table(ctx);
-	while (bs->cachebits % 8 != 0) { /* cabac_alignment_one_bit */
-		CHK(orc_bs_read_bits(bs, &v, 1) < 0 ? -EIO : 0);
-		if (v != 1)
-			return -EIO;
-	}
-	orc_cabac_init_states((int)type, sh->cabac_init_idc,
-			      ctx->derived.SliceQPLuma, init);
-	for (i = 0; i < 1024; i++) {
-		st[i].idx = init[i][0];
-		st[i].mps = init[i][1];
-	}
-	d.bs = bs;
-	d.range = 510;
-	CHK(dec_bits(&d, 9, &d.offset));
-
-	addr = sh->first_mb_in_slice;
-	for (;;) {
-		struct orc_mb *mb;
-		struct orc_mb_info *info;
-		if (mb_count >= H264_AMD_MAX_SLICE_MBS)
-			return H264_AMD_E_MB_OVERFLOW;
-		CHK(orc_new_macroblock(ctx, addr, 0, -1));
-		mb = ctx->mb;
-		if (type != H264_SLICE_TYPE_I && type != H264_SLICE_TYPE_SI) {
-			uint32_t off = type == H264_SLICE_TYPE_B ? 24 : 11;
-			CHK(dec_decision(&d,
-					 &st[off + inc_skip(mb->infoA) +
-					     inc_skip(mb->infoB)],
-					 &bin));
-			if (!bin)
-				return H264_AMD_E_UNSUPPORTED; /* a coded P/B MB */
-			CHK(orc_new_macroblock(ctx, addr, 1, -1));
-			mb = ctx->mb;
-			prev_qp_nonzero = 0;
-		} else {
-			uint32_t pred, k;
-			int32_t qpd;
-			if (type == H264_SLICE_TYPE_SI)
-				return H264_AMD_E_UNSUPPORTED; /* mb_type prefix */
-			info = &ctx->slice.mb_table
-					.info[addr - sh->first_mb_in_slice];
-			/* mb_type, Table 9-36: 1 [terminate 0] luma chroma.. */
-			CHK(dec_decision(&d,
-					 &st[3 + inc_mb_type(mb->infoA, 3) +
-					     inc_mb_type(mb->infoB, 3)],
-					 &bin));
-			if (!bin)
-				return H264_AMD_E_UNSUPPORTED; /* I_NxN */
-			CHK(dec_terminate(&d, &bin));
-			if (bin)
-				return H264_AMD_E_UNSUPPORTED; /* I_PCM */
-			CHK(dec_decision(&d, &st[3 + 3], &bin));
-			if (bin)
-				return H264_AMD_E_UNSUPPORTED; /* luma AC coded */
-			CHK(dec_decision(&d, &st[3 + 4], &bin));
-			if (bin)
-				return H264_AMD_E_UNSUPPORTED; /* chroma coded */
-			CHK(dec_decision(&d, &st[3 + 6], &bin));
-			pred = (uint32_t)bin << 1;
-			CHK(dec_decision(&d, &st[3 + 7], &bin));
-			pred |= (uint32_t)bin;
-			mb->raw_mb_type = 1 + pred;
-			mb->mb_type = H264_MB_TYPE_I_16x16;
-			mb->NumMbPart = 1;
-			mb->MbPartPredMode[0] = ORC_PRED_Intra_16x16;
-			mb->Intra16x16PredMode = pred;
-			info->mb_type = H264_MB_TYPE_I_16x16;
-			if (cat == 3)
-				return H264_AMD_E_UNSUPPORTED; /* Cb/Cr as luma */
-			if (cat != 0) {
-				/* intra_chroma_pred_mode: TU, cMax 3 */
-				CHK(dec_decision(&d,
-						 &st[64 + inc_chroma_pred(mb->infoA) +
-						     inc_chroma_pred(mb->infoB)],
-						 &bin));
-				k = (uint32_t)bin;
-				if (k == 1) {
-					CHK(dec_decision(&d, &st[64 + 3], &bin));
-					k += (uint32_t)bin;
-				}
-				if (k == 2) {
-					CHK(dec_decision(&d, &st[64 + 3], &bin));
-					k += (uint32_t)bin;
-				}
-				mb->intra_chroma_pred_mode = k;
-				info->intra_chroma_pred_mode = (uint8_t)k;
-			}
-			/* mb_qp_delta: unary, mapped (9.3.2.7, Table 9-3) */
-			CHK(dec_decision(&d, &st[60 + (prev_qp_nonzero ? 1 : 0)],
-					 &bin));
-			k = 0;
-			if (bin) {
-				k = 1;
-				CHK(dec_decision(&d, &st[60 + 2], &bin));
-				while (bin) {
-					if (++k > 255)
-						return -EIO;
-					CHK(dec_decision(&d, &st[60 + 3], &bin));
-				}
-			}
-			qpd = (k & 1) ? (int32_t)((k + 1) / 2) : -(int32_t)(k / 2);
-			mb->mb_qp_delta = qpd;
-			prev_qp_nonzero = qpd != 0;
-			/* coded_block_flag of Intra16x16DCLevel (ctxBlockCat 0) */
-			CHK(dec_decision(&d,
-					 &st[85 + (mb->infoA == NULL ? 1 : 0) +
-					     2 * (mb->infoB == NULL ? 1 : 0)],
-					 &bin));
-			if (bin)
-				return H264_AMD_E_UNSUPPORTED; /* residual */
-		}
-		if (rd->cbs.slice_data_mb)
-			rd->cbs.slice_data_mb(ctx, sh, mb->mbAddr, mb->mb_type,
-					      rd->userdata);
-		addr++;
-		mb_count++;
-		CHK(dec_terminate(&d, &bin)); /* end_of_slice_flag */
-		if (bin)
-			break;
-	}
-	if (rd->cbs.slice_data_end)
-		rd->cbs.slice_data_end(ctx, sh, mb_count, rd->userdata);
-	return 0;
-}
-
 /* ---- synthetic slices (ref src/h264_writer.c:49-309) ------------------- */
 static int setup_grey_mb(struct orc_ctx *ctx, uint32_t i)
 {

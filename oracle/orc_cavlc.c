@@ -135,7 +135,7 @@ static int read_vlc(struct h264_bitstream *bs, const struct vlc *t,
 
 /* ---- macroblock table (ref src/h264_slice_data.c:1098-1232) ------------ */
 
-static uint32_t mb_off(const struct orc_ctx *ctx, uint32_t mbAddr)
+uint32_t orc_mb_off(const struct orc_ctx *ctx, uint32_t mbAddr)
 {
 	return mbAddr - ctx->slice.hdr.first_mb_in_slice *
 				(1 + ctx->derived.MbaffFrameFlag);
@@ -164,7 +164,7 @@ static void compute_neighbours(struct orc_ctx *ctx, struct orc_mb *mb)
 	}
 	if (mb->mbAddrA != ORC_MB_ADDR_INVALID) {
 		struct orc_mb_info *i =
-			&ctx->slice.mb_table.info[mb_off(ctx, mb->mbAddrA)];
+			&ctx->slice.mb_table.info[orc_mb_off(ctx, mb->mbAddrA)];
 		if (!i->available)
 			mb->mbAddrA = ORC_MB_ADDR_INVALID;
 		else
@@ -172,7 +172,7 @@ static void compute_neighbours(struct orc_ctx *ctx, struct orc_mb *mb)
 	}
 	if (mb->mbAddrB != ORC_MB_ADDR_INVALID) {
 		struct orc_mb_info *i =
-			&ctx->slice.mb_table.info[mb_off(ctx, mb->mbAddrB)];
+			&ctx->slice.mb_table.info[orc_mb_off(ctx, mb->mbAddrB)];
 		if (!i->available)
 			mb->mbAddrB = ORC_MB_ADDR_INVALID;
 		else
@@ -184,7 +184,7 @@ int orc_new_macroblock(struct orc_ctx *ctx, uint32_t mbAddr, int skipped,
 		       int field_flag)
 {
 	const struct h264_slice_header *sh = &ctx->slice.hdr;
-	uint32_t off = mb_off(ctx, mbAddr);
+	uint32_t off = orc_mb_off(ctx, mbAddr);
 	struct orc_mb *mb;
 
 	/* an MBAFF frame slice with first_mb_in_slice > 0 reaches here through the
@@ -281,21 +281,21 @@ int orc_new_macroblock(struct orc_ctx *ctx, uint32_t mbAddr, int skipped,
 static void set_nz(struct orc_ctx *ctx, uint32_t mbAddr, uint32_t comp,
 		   uint32_t idx, uint32_t n)
 {
-	ctx->slice.mb_table.info[mb_off(ctx, mbAddr)].nz_coeff[comp * 16 + idx] =
+	ctx->slice.mb_table.info[orc_mb_off(ctx, mbAddr)].nz_coeff[comp * 16 + idx] =
 		n;
 }
 
 static uint32_t get_nz(struct orc_ctx *ctx, uint32_t mbAddr, uint32_t comp,
 		       uint32_t idx)
 {
-	return ctx->slice.mb_table.info[mb_off(ctx, mbAddr)]
+	return ctx->slice.mb_table.info[orc_mb_off(ctx, mbAddr)]
 		.nz_coeff[comp * 16 + idx];
 }
 
 /* ---- 4x4 block neighbours (ref src/h264_macroblock.c:35-104,275-433) --- */
 
 /* 6.4.12.1 / 6.4.12.2 (ref src/h264_macroblock.c:84-231) */
-static void neigh_loc(const struct orc_ctx *ctx, const struct orc_mb *mb,
+void orc_neigh_loc(const struct orc_ctx *ctx, const struct orc_mb *mb,
 		      uint32_t maxW, uint32_t maxH, int32_t xN, int32_t yN,
 		      uint32_t *addrN, uint32_t *xW, uint32_t *yW)
 {
@@ -408,7 +408,7 @@ static void neigh_loc(const struct orc_ctx *ctx, const struct orc_mb *mb,
 	*yW = yM < 0 ? (uint32_t)(yM + (int32_t)maxH) : (uint32_t)yM;
 }
 
-static void neigh_luma4x4(const struct orc_ctx *ctx, const struct orc_mb *mb,
+void orc_neigh_luma4x4(const struct orc_ctx *ctx, const struct orc_mb *mb,
 			  uint32_t idx,
 			  uint32_t *addrA, uint32_t *idxA, uint32_t *addrB,
 			  uint32_t *idxB)
@@ -423,22 +423,22 @@ static void neigh_luma4x4(const struct orc_ctx *ctx, const struct orc_mb *mb,
 		{0, 2, 8, 10}, {1, 3, 9, 11}, {4, 6, 12, 14}, {5, 7, 13, 15}};
 	uint32_t xW, yW;
 	int32_t x = pos[idx][0], y = pos[idx][1];
-	neigh_loc(ctx, mb, 16, 16, x - 1, y, addrA, &xW, &yW);
+	orc_neigh_loc(ctx, mb, 16, 16, x - 1, y, addrA, &xW, &yW);
 	*idxA = at[xW / 4][yW / 4];
-	neigh_loc(ctx, mb, 16, 16, x, y - 1, addrB, &xW, &yW);
+	orc_neigh_loc(ctx, mb, 16, 16, x, y - 1, addrB, &xW, &yW);
 	*idxB = at[xW / 4][yW / 4];
 }
 
-static void neigh_chroma4x4(const struct orc_ctx *ctx, const struct orc_mb *mb,
+void orc_neigh_chroma4x4(const struct orc_ctx *ctx, const struct orc_mb *mb,
 			    uint32_t idx, uint32_t *addrA, uint32_t *idxA,
 			    uint32_t *addrB, uint32_t *idxB)
 {
 	uint32_t xW, yW;
 	int32_t x = 4 * (idx & 1), y = 4 * (idx >> 1);
 	uint32_t mw = ctx->sps_derived.MbWidthC, mh = ctx->sps_derived.MbHeightC;
-	neigh_loc(ctx, mb, mw, mh, x - 1, y, addrA, &xW, &yW);
+	orc_neigh_loc(ctx, mb, mw, mh, x - 1, y, addrA, &xW, &yW);
 	*idxA = 2 * (yW / 4) + xW / 4;
-	neigh_loc(ctx, mb, mw, mh, x, y - 1, addrB, &xW, &yW);
+	orc_neigh_loc(ctx, mb, mw, mh, x, y - 1, addrB, &xW, &yW);
 	*idxB = 2 * (yW / 4) + xW / 4;
 }
 
@@ -461,9 +461,9 @@ static int read_coeff_token(struct h264_bitstream *bs, struct orc_ctx *ctx,
 	if (kind == ORC_LVL_CHROMA_AC) {
 		if (blkIdx >= 8)
 			return -EPROTO;
-		neigh_chroma4x4(ctx, mb, blkIdx, &addrA, &idxA, &addrB, &idxB);
+		orc_neigh_chroma4x4(ctx, mb, blkIdx, &addrA, &idxA, &addrB, &idxB);
 	} else {
-		neigh_luma4x4(ctx, mb, blkIdx, &addrA, &idxA, &addrB, &idxB);
+		orc_neigh_luma4x4(ctx, mb, blkIdx, &addrA, &idxA, &addrB, &idxB);
 	}
 	availA = addrA != ORC_MB_ADDR_INVALID;
 	availB = addrB != ORC_MB_ADDR_INVALID;
@@ -739,8 +739,7 @@ static int residual(struct h264_bitstream *bs, struct orc_ctx *ctx,
 }
 
 /* ---- 7.4.5 mb_type (ref src/h264_slice_data.c:839-969) ----------------- */
-static int read_mb_type(struct h264_bitstream *bs, struct orc_ctx *ctx,
-			struct orc_mb *mb)
+int orc_apply_mb_type(struct orc_ctx *ctx, struct orc_mb *mb, uint32_t type)
 {
 	/* B_16x8 / B_8x16 partition prediction modes, mb_type 4..21 */
 	static const uint8_t bmode[18][2] = {
@@ -754,9 +753,7 @@ static int read_mb_type(struct h264_bitstream *bs, struct orc_ctx *ctx,
 		{ORC_PRED_Bi, ORC_PRED_L1}, {ORC_PRED_Bi, ORC_PRED_L1},
 		{ORC_PRED_Bi, ORC_PRED_Bi}, {ORC_PRED_Bi, ORC_PRED_Bi},
 	};
-	uint32_t type = 0;
 	int intra = 0;
-	CHK(orc_bs_read_ue(bs, &type));
 	mb->raw_mb_type = type;
 
 	switch (ctx->slice.type) {
@@ -844,14 +841,22 @@ static int read_mb_type(struct h264_bitstream *bs, struct orc_ctx *ctx,
 		}
 	}
 	/* 4-bit field in the reference (Appendix C.3) */
-	ctx->slice.mb_table.info[mb_off(ctx, mb->mbAddr)].mb_type =
+	ctx->slice.mb_table.info[orc_mb_off(ctx, mb->mbAddr)].mb_type =
 		mb->mb_type & 0xf;
 	return 0;
 }
 
-/* ref src/h264_slice_data.c:975-1035 */
-static int read_sub_mb_type(struct h264_bitstream *bs, struct orc_ctx *ctx,
-			    struct orc_mb *mb)
+static int read_mb_type(struct h264_bitstream *bs, struct orc_ctx *ctx,
+			struct orc_mb *mb)
+{
+	uint32_t type = 0;
+	CHK(orc_bs_read_ue(bs, &type));
+	return orc_apply_mb_type(ctx, mb, type);
+}
+
+/* ref src/h264_slice_data.c:975-1035; the table step for one sub-macroblock */
+int orc_apply_sub_mb_type(struct orc_ctx *ctx, struct orc_mb *mb, uint32_t p,
+			  uint32_t type)
 {
 	static const uint8_t tp[4][3] = {
 		{ORC_SUB_P_8x8, 1, ORC_PRED_L0},
@@ -874,10 +879,8 @@ static int read_sub_mb_type(struct h264_bitstream *bs, struct orc_ctx *ctx,
 		{ORC_SUB_B_4x4, 4, ORC_PRED_L1},
 		{ORC_SUB_B_4x4, 4, ORC_PRED_Bi},
 	};
-	uint32_t p, type = 0;
-	for (p = 0; p < 4; p++) {
+	{
 		const uint8_t *row = NULL;
-		CHK(orc_bs_read_ue(bs, &type));
 		mb->raw_sub_mb_type[p] = type;
 		if (ctx->slice.type == H264_SLICE_TYPE_P ||
 		    ctx->slice.type == H264_SLICE_TYPE_SP) {
@@ -894,6 +897,17 @@ static int read_sub_mb_type(struct h264_bitstream *bs, struct orc_ctx *ctx,
 			mb->NumSubMbPart[p] = row[1];
 			mb->SubMbPredMode[p] = row[2];
 		}
+	}
+	return 0;
+}
+
+static int read_sub_mb_type(struct h264_bitstream *bs, struct orc_ctx *ctx,
+			    struct orc_mb *mb)
+{
+	uint32_t p, type = 0;
+	for (p = 0; p < 4; p++) {
+		CHK(orc_bs_read_ue(bs, &type));
+		CHK(orc_apply_sub_mb_type(ctx, mb, p, type));
 	}
 	return 0;
 }
@@ -1150,10 +1164,10 @@ static int slice_data_internal(struct h264_bitstream *bs, struct orc_reader *rd)
 	int res;
 
 	if (ctx->pps->entropy_coding_mode_flag) {
-		/* CABAC is not parsed (Appendix C.1) unless the engine's subset
+		/* CABAC is not parsed (Appendix C.1) unless the engine's CABAC
 		 * decoder is asked for */
-		if (rd->flags & H264_AMD_READER_FLAGS_CABAC_SUBSET)
-			return orc_cabac_subset_slice_data(bs, rd);
+		if (rd->flags & H264_AMD_READER_FLAGS_CABAC)
+			return orc_cabac_slice_data(bs, rd);
 		return 0;
 	}
 	/* deviation shared with the product (h264_amd.h): the reference takes
@@ -1256,7 +1270,7 @@ void orc_mb_to_record(const struct orc_ctx *ctx, uint8_t *rec, uint32_t stride)
 {
 	const struct orc_mb *mb = ctx->mb;
 	const struct orc_mb_info *info =
-		&ctx->slice.mb_table.info[mb_off(ctx, mb->mbAddr)];
+		&ctx->slice.mb_table.info[orc_mb_off(ctx, mb->mbAddr)];
 	struct h264_amd_mb_summary *s = (struct h264_amd_mb_summary *)rec;
 	uint32_t cat = ctx->sps_derived.ChromaArrayType;
 	int16_t *co = (int16_t *)(rec + H264_AMD_T2_HEAD);

@@ -1,5 +1,6 @@
-"""CABAC subset decoder (engine extension, H264_AMD_READER_FLAGS_CABAC_SUBSET):
-the oracle's CPU statement of it against (i) the reference writers' restatement
+"""CABAC decoder (engine extension, H264_AMD_READER_FLAGS_CABAC) on the subset of
+the syntax the REFERENCE's writers emit -- the part of CABAC decoding that has
+reference behaviour to pin against.  The oracle's CPU statement of it against (i) the reference writers' restatement
 (round trip: what h264_write_grey_i_slice / h264_write_skipped_p_slice emit
 must decode to exactly the macroblocks that were asked for) and (ii) an
 independent Python CABAC encoder with values those writers never produce.
@@ -149,16 +150,17 @@ def test_values_the_writers_never_emit(width, cf):
         assert (rec[:, 3] == 1 + rec[:, 7]).all()
 
 
-def test_leaving_the_subset_is_reported():
-    """4:4:4 intra, SI slices and damaged data end with E_UNSUPPORTED / -EIO,
+def test_unsupported_and_damaged_are_reported():
+    """MBAFF frames with CABAC end with E_UNSUPPORTED, damaged data with -EIO,
     never with a wrong macroblock count."""
-    sps, pps = param_sets(8, 6, 3)
-    sps.profile_idc = 244
-    b = orc.Builder()
-    head = [b.nalu(3, 7, sps=sps), b.nalu(3, 8, sps=sps, pps=pps)]
-    nal = custom_i_slice(b, sps, pps, [(1, 0, 0)] * 5, 0, 0)
-    r = orc.parse_nalus(head + [nal], flags=FLAGS).results[0]
+    import streams
+    from libh264_amd import gen
+    cfg = streams.small_cfg(entropy_coding_mode_flag=1, field_coding=2)
+    nal = gen.slice_nal(cfg, streams.rich_slice(cfg, 1, 2, cabac_payload=40))
+    r = orc.parse_nalus([gen.sps(cfg), gen.pps(cfg), nal],
+                        flags=FLAGS).results[0]
     assert (r.status, r.mb_count, r.flags) == (-38, 0, 5)
+    b = orc.Builder()
     sps, pps = param_sets(8, 6, 1)
     head = [b.nalu(3, 7, sps=sps), b.nalu(3, 8, sps=sps, pps=pps)]
     good = custom_i_slice(b, sps, pps, [(1, 2, -1)] * 48, 0, 0)
@@ -166,4 +168,4 @@ def test_leaving_the_subset_is_reported():
     assert (r.status, r.mb_count) == (0, 48)
     cut = good[:len(good) - 6]
     r = orc.parse_nalus(head + [cut], flags=FLAGS).results[0]
-    assert r.status in (-5, -38) and r.mb_count < 48
+    assert r.status == -5 and r.mb_count < 48
