@@ -102,7 +102,7 @@ def build_engine(force=False):
             "H264_AMD_HIPCC_OPT",
             "-O3 -mllvm -structurizecfg-skip-uniform-regions").split()
         _run([_hipcc(), "--offload-arch=gfx950"] + opt + ["-std=c++17", "-fPIC",
-              "-shared", "-Wno-unused-value", "-I" + INC, "-I" + CSRC,
+              "-shared", "-Wno-unused-value", "-Wno-inline-asm", "-I" + INC, "-I" + CSRC,
               '-DH264_AMD_BUILD_ID="%s"' % sid,
               os.path.join(CSRC, "engine.hip"), "-o", out])
     return out

@@ -27,7 +27,7 @@
 #include "kernels/scan.hip"
 #include "kernels/slice_decode.hip"
 #include "kernels/slice_write.hip"
-#include "kernels/cabac_decode.hip"
+#include "kernels/cabac_slice.hip"
 
 /* ---- helpers --------------------------------------------------------------- */
 
@@ -91,6 +91,10 @@ struct h264_amd_engine {
 	bool own_stream;
 	dev_vlc_tables *d_vlc;
 	cabac_tables *d_cabac;
+	cabac_dec_tables *d_cabac_dec;
+	uint32_t *d_cabac_bins; /* bins per slice of the last CABAC pass */
+	size_t cap_cabac_bins;
+	uint32_t cabac_bins_n;
 	/* device copy of the last params object used */
 	const h264_amd_params *params_src;
 	uint64_t params_serial;
@@ -277,6 +281,13 @@ extern "C" int h264_amd_engine_new(int device, void *hip_stream,
 		NEW_TRY(hipMemcpy(e->d_cabac, h, sizeof(*h), hipMemcpyHostToDevice));
 		delete h;
 	}
+	{
+		cabac_dec_tables *h = new cabac_dec_tables;
+		cabac_dec_build_tables(h);
+		NEW_TRY(hipMalloc((void **)&e->d_cabac_dec, sizeof(*h)));
+		NEW_TRY(hipMemcpy(e->d_cabac_dec, h, sizeof(*h), hipMemcpyHostToDevice));
+		delete h;
+	}
 #undef NEW_TRY
 	*ret = e;
 	return 0;
@@ -295,6 +306,8 @@ extern "C" int h264_amd_engine_destroy(struct h264_amd_engine *e)
 				hipEventDestroy(e->ev[f][k]);
 	hipFree(e->d_vlc);
 	hipFree(e->d_cabac);
+	hipFree(e->d_cabac_dec);
+	hipFree(e->d_cabac_bins);
 	hipFree(e->d_sps);
 	hipFree(e->d_pps);
 	hipFree(e->d_fmo);
@@ -648,7 +661,7 @@ extern "C" int h264_amd_decode_slices(struct h264_amd_engine *e,
 	if (((uintptr_t)args->d_descs & 7u) || ((uintptr_t)args->d_results & 15u) ||
 	    ((uintptr_t)args->d_headers & 15u))
 		return -EINVAL;
-	if ((args->reader_flags & H264_AMD_READER_FLAGS_CABAC_SUBSET) &&
+	if ((args->reader_flags & H264_AMD_READER_FLAGS_CABAC) &&
 	    args->d_headers == NULL)
 		return -EINVAL; /* the CABAC pass reads the header images */
 	uint32_t stride = args->mb_stride;
@@ -779,10 +792,10 @@ extern "C" int h264_amd_decode_slices(struct h264_amd_engine *e,
 	HIP_TRY(hipEventRecord(e->ev[FAM_DECODE][1], e->stream));
 	e->timed[FAM_DECODE] = true;
 
-	if ((args->reader_flags & H264_AMD_READER_FLAGS_CABAC_SUBSET) &&
+	if ((args->reader_flags & H264_AMD_READER_FLAGS_CABAC) &&
 	    (args->reader_flags & H264_READER_FLAGS_SLICE_DATA)) {
 		/* second pass over the slices the first one flagged as CABAC */
-		cb_args c;
+		cs_args c;
 		memset(&c, 0, sizeof(c));
 		c.buf = a.buf;
 		c.descs = a.descs;
@@ -794,6 +807,7 @@ extern "C" int h264_amd_decode_slices(struct h264_amd_engine *e,
 		c.n_pps = a.n_pps;
 		c.n_epochs = a.n_epochs;
 		c.tab = e->d_cabac;
+		c.dtab = e->d_cabac_dec;
 		c.tier = a.tier;
 		c.mb_capacity = a.mb_capacity;
 		c.mb_stride = a.mb_stride;
@@ -801,17 +815,38 @@ extern "C" int h264_amd_decode_slices(struct h264_amd_engine *e,
 		c.headers = a.headers;
 		c.mb_out = a.mb_out;
 		c.row_pitch = a.row_pitch;
-		c.prio_div = c.n > 4u * e->cu_count ? 4u * e->cu_count : 0u;
-		size_t clds = CB_ROW_OFF + (((size_t)c.row_pitch + 15u) & ~(size_t)15u);
+		c.wave_lds_bytes =
+			(CS_ROW_OFF + CS_ROW_STRIDE * c.row_pitch + 255u) & ~255u;
+		{
+			const uint32_t wgs = (c.n + CS_WAVES_PER_BLOCK - 1) / CS_WAVES_PER_BLOCK;
+			const uint32_t cap = e->cu_count * 16u;
+			c.prio_div = wgs > e->cu_count && (c.n <= cap || c.n % cap == 0)
+					     ? e->cu_count
+					     : 0u;
+		}
+		if (c.n > e->cap_cabac_bins) {
+			hipFree(e->d_cabac_bins);
+			e->d_cabac_bins = NULL;
+			e->cap_cabac_bins = 0;
+			HIP_TRY(hipMalloc((void **)&e->d_cabac_bins,
+					  (size_t)c.n * sizeof(uint32_t)));
+			e->cap_cabac_bins = c.n;
+		}
+		HIP_TRY(hipMemsetAsync(e->d_cabac_bins, 0, (size_t)c.n * sizeof(uint32_t),
+				       e->stream));
+		c.bins = e->d_cabac_bins;
+		e->cabac_bins_n = c.n;
+		size_t clds = CS_MN_BYTES + (size_t)CS_WAVES_PER_BLOCK * c.wave_lds_bytes;
 		if (clds > 160u * 1024u)
 			return -E2BIG;
 		if (clds > 48u * 1024u)
 			HIP_TRY(hipFuncSetAttribute(
-				(const void *)h264_amd_k_decode_cabac_subset,
+				(const void *)h264_amd_k_decode_cabac,
 				hipFuncAttributeMaxDynamicSharedMemorySize, (int)clds));
 		HIP_TRY(hipEventRecord(e->ev[FAM_CABAC][0], e->stream));
-		hipLaunchKernelGGL(h264_amd_k_decode_cabac_subset, dim3(c.n), dim3(64),
-				   clds, e->stream, c);
+		hipLaunchKernelGGL(h264_amd_k_decode_cabac,
+				   dim3((c.n + CS_WAVES_PER_BLOCK - 1) / CS_WAVES_PER_BLOCK),
+				   dim3(64 * CS_WAVES_PER_BLOCK), clds, e->stream, c);
 		HIP_TRY(hipGetLastError());
 		HIP_TRY(hipEventRecord(e->ev[FAM_CABAC][1], e->stream));
 		e->timed[FAM_CABAC] = true;

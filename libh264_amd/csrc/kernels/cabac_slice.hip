@@ -1,0 +1,1496 @@
+/**
+ * cabac_slice.hip -- CABAC slice data on gfx950 (H264_AMD_READER_FLAGS_CABAC,
+ * include/h264_amd.h): the whole macroblock layer of I / SI / P / SP / B slices,
+ * frame and field pictures, all chroma formats, 8x8 transform, I_PCM.
+ *
+ * NOT reference behaviour: the reference returns before any CABAC slice data
+ * (src/h264_syntax_slice_data.h:715-717) and so does h264_amd_k_decode_slices.
+ * This second kernel runs after it, on the slices it flagged
+ * H264_AMD_SR_CABAC.  Written from the standard (7.3.4 / 7.3.5 syntax, 9.3
+ * binarisations, context index rules, decoding engine); spec-only, "parity
+ * unpinned", except that it is the exact inverse of the reference's ENCODER on
+ * what that encoder emits (src/h264_bac.c:253-358, src/h264_cabac.c:61-975,
+ * src/h264_writer.c:79-129,177-219) and that the context variables are
+ * initialised the reference's way (src/h264_bac.c:216-230,
+ * src/h264_cabac_ctx_tables.c:4441-4468).  CPU twin with the same conventions
+ * and the same behaviour on damaged input: oracle/orc_cabac_dec.c.
+ *
+ * One slice per wavefront, four per workgroup.  How the 64 lanes are used:
+ *   * the (m, n) tables of all 1024 contexts sit in LDS, shared by the
+ *     workgroup ("h264_cabac_ctx_tables resident in LDS"); the context
+ *     VARIABLES live in 14 vector registers, one context per lane, grouped by
+ *     syntax element so that a call site names its register statically: a
+ *     state is read with one v_readlane and written with one v_writelane
+ *     instead of an LDS round trip (54+ cycles on the bin-serial chain);
+ *   * rangeTabLPS, the state transitions and Table 9-43 are vector registers
+ *     too, one table row per lane;
+ *   * the arithmetic decoder (codIRange, codIOffset scaled by up to 23 bits of
+ *     read-ahead, so that renormalisation is a subtraction from a counter and
+ *     the stream is touched once per 16 bits) is wave-uniform;
+ *   * what ctxIdxInc asks of the neighbouring blocks -- coded_block_flag,
+ *     |mvd|, ref_idx > 0 -- is kept as 5x5 (3x5, 3x3) GRIDS across the lanes of
+ *     a register: current macroblock in the middle, the left macroblock's right
+ *     column and the upper macroblock's bottom row (from the LDS row context)
+ *     as the border, "not available" already folded into the border values.
+ *     A ctxIdxInc is two v_readlane, without a case for "block on the edge";
+ *   * the 64 dwords of a T2 record's head are one register (v_writelane per
+ *     field), the coefficients of the block being decoded another (lane =
+ *     scanning position), stored with one ds_write per lane;
+ *   * with ChromaArrayType 3 the per-component register sets rotate at the
+ *     component switch, so the residual code exists once.
+ */
+#ifndef H264_AMD_CABAC_SLICE_HIP
+#define H264_AMD_CABAC_SLICE_HIP
+
+/* engine.hip includes slice_decode.hip and slice_write.hip before this file:
+ * OutCtx / sd_emit_* / WaveBits / sw_activate / cabac_tables / cabac_state_init */
+
+#define CS_WAVES_PER_BLOCK 4u
+#define CS_MN_BYTES 8192u /* int8 (m, n)[1024][4] */
+/* per wave */
+#define CS_RING_OFF 0u
+#define CS_STATE_OFF 1024u
+#define CS_STAGE_OFF (1024u + WB_STATE_BYTES)
+#define CS_STAGE_BYTES 2048u /* largest T2 record: 1792 B */
+#define CS_ROW_OFF (CS_STAGE_OFF + CS_STAGE_BYTES)
+#define CS_ROW_STRIDE 40u
+
+/* row context of one macroblock column (what the macroblock below looks at):
+ *   [0,4)   flags | cbp << 8 | DC coded_block_flags << 16
+ *   [4,8)   coded_block_flag of the bottom row of luma 4x4 blocks
+ *   [8,16)  ChromaArrayType 3: the same for Cb, Cr; else chroma AC bottom rows
+ *           (Cb at 8, 9; Cr at 10, 11)
+ *   [16,28) list 0: |mvd x| and |mvd y| of the bottom row (clamped to 255),
+ *           ref_idx of the bottom 8x8 blocks;  [28,40) list 1 */
+#define CS_NB_VALID 0x80u
+#define CS_NB_SKIP 0x01u
+#define CS_NB_ICPNZ 0x02u /* intra_chroma_pred_mode != 0 */
+#define CS_NB_T8 0x04u
+#define CS_NB_PCM 0x08u
+#define CS_NB_INXN 0x10u /* mb_type I_NxN */
+#define CS_NB_SI 0x20u
+#define CS_NB_BDIR 0x40u /* B_Skip or B_Direct_16x16 */
+
+/* registers holding context variables */
+enum { CX_MB0, CX_MB1, CX_SIG, CX_LAST = CX_SIG + 3, CX_ABS = CX_LAST + 3,
+       CX_M8 = CX_ABS + 3, CX_REGS = CX_M8 + 3 };
+/* lanes inside the per-component registers */
+#define CXL_SIG8 0u /* CX_M8: significant_coeff_flag of 8x8 blocks, 15 */
+#define CXL_LAST8 15u /* 9 */
+#define CXL_CBF8 24u /* coded_block_flag of 8x8 blocks (4:4:4), 4 */
+#define CXL_CBF 28u /* coded_block_flag DC / AC / 4x4: + 0 / 4 / 8 + inc */
+#define CXL_ABS8 49u /* CX_ABS: coeff_abs_level_minus1 of 8x8 blocks, 10 */
+/* CX_MB1 holds ctxIdx 64 .. 104 at lane ctxIdx - 64 and transform_size_8x8_flag
+ * (399 .. 401) at lanes 41 .. 43 */
+#define CXL_T8 41u
+
+struct cabac_dec_tables {
+	uint16_t slot_ctx[2][CX_REGS][64]; /* [field][register][lane] -> ctxIdx */
+	uint16_t pos8[2][64]; /* Table 9-43: sig8 | last8 << 8, [field][levelListIdx] */
+};
+
+static void cabac_dec_build_tables(cabac_dec_tables *t)
+{
+#define H264_CRT(type, name, dims, ...) static const type crt_##name dims = __VA_ARGS__;
+#include "../common/h264_cabac_residual_tables.inc"
+#undef H264_CRT
+	memset(t, 0xff, sizeof(*t));
+	for (int f = 0; f < 2; f++) {
+		for (int l = 0; l < 64; l++) {
+			t->slot_ctx[f][CX_MB0][l] = (uint16_t)l;
+			if (l <= 40)
+				t->slot_ctx[f][CX_MB1][l] = (uint16_t)(64 + l);
+			else if (l <= 43)
+				t->slot_ctx[f][CX_MB1][l] = (uint16_t)(399 + l - 41);
+		}
+		for (int c = 0; c < 3; c++) {
+			/* ctxBlockCat of the DC block of the component and of its
+			 * 8x8 block */
+			const int cat0 = c == 0 ? 0 : c == 1 ? 6 : 10, cat8 = 5 + 4 * c;
+			const int nsl = c == 0 ? 61 : 44; /* luma set also holds chroma DC / AC */
+			for (int l = 0; l < nsl; l++) {
+				t->slot_ctx[f][CX_SIG + c][l] =
+					(uint16_t)(crt_sig_base[f][cat0] + l);
+				t->slot_ctx[f][CX_LAST + c][l] =
+					(uint16_t)(crt_last_base[f][cat0] + l);
+			}
+			for (int l = 0; l < (c == 0 ? 49 : 30); l++)
+				t->slot_ctx[f][CX_ABS + c][l] =
+					(uint16_t)(crt_abs_base[cat0] + l);
+			for (int l = 0; l < 10; l++)
+				t->slot_ctx[f][CX_ABS + c][CXL_ABS8 + l] =
+					(uint16_t)(crt_abs_base[cat8] + l);
+			for (int l = 0; l < 15; l++)
+				t->slot_ctx[f][CX_M8 + c][CXL_SIG8 + l] =
+					(uint16_t)(crt_sig_base[f][cat8] + l);
+			for (int l = 0; l < 9; l++)
+				t->slot_ctx[f][CX_M8 + c][CXL_LAST8 + l] =
+					(uint16_t)(crt_last_base[f][cat8] + l);
+			for (int l = 0; l < 4; l++)
+				t->slot_ctx[f][CX_M8 + c][CXL_CBF8 + l] =
+					(uint16_t)(crt_cbf_base[cat8] + l);
+			for (int l = 0; l < 12; l++)
+				t->slot_ctx[f][CX_M8 + c][CXL_CBF + l] =
+					(uint16_t)(crt_cbf_base[cat0] + l);
+		}
+		for (int l = 0; l < 64; l++)
+			t->pos8[f][l] = l < 63 ? (uint16_t)(crt_sig8[f][l] |
+							    (crt_last8[l] << 8))
+					       : 0;
+	}
+}
+
+struct cs_args {
+	const uint8_t *buf;
+	const struct h264_amd_slice_desc *descs;
+	uint32_t n;
+	const dev_sps *spsv;
+	const dev_pps *ppsv;
+	const dev_epoch *epochs;
+	uint32_t n_sps, n_pps, n_epochs;
+	const cabac_tables *tab;
+	const cabac_dec_tables *dtab;
+	uint32_t tier, mb_capacity, mb_stride;
+	struct h264_amd_slice_result *results;
+	const struct h264_slice_header *headers;
+	uint8_t *mb_out;
+	uint32_t row_pitch; /* macroblock columns of row context in LDS */
+	uint32_t wave_lds_bytes;
+	/* workgroups per dispatch layer (see slice_decode.hip, "fair shares");
+	 * 0: no priority rotation */
+	uint32_t prio_div;
+	/* optional [n]: bins decoded per slice (bench statistics) */
+	uint32_t *bins;
+};
+
+__device__ __forceinline__ uint32_t cb_hdr(const struct h264_slice_header *h,
+					   uint32_t off)
+{
+	return wb_uniform(*reinterpret_cast<const uint32_t *>(
+		reinterpret_cast<const uint8_t *>(h) + off));
+}
+
+/* ---- decoding engine (9.3.1.2, 9.3.3.2), wave-uniform ------------------------ */
+struct CbEng {
+	/* codIOffset << k | the next k bits of the stream; codIRange; k <= 23 */
+	uint32_t V, range, k;
+	uint32_t bins;
+	/* per lane: rangeTabLPS[lane][0..3]; transIdxLPS | flip << 6 | transIdxMPS
+	 * << 8 (flip: valMPS changes on an LPS in state 0); Table 9-43 */
+	uint32_t lps4, trans, pos8;
+};
+
+__device__ __forceinline__ uint32_t cs_rl(uint32_t v, uint32_t l)
+{
+	return (uint32_t)__builtin_amdgcn_readlane((int)v, (int)l);
+}
+
+/* v_writelane_b32 (this clang has no builtin for it).  gfx9 allows one scalar
+ * register per vector instruction, so the lane select travels in M0 */
+__device__ __forceinline__ uint32_t cs_wl(uint32_t vec, uint32_t val, uint32_t l)
+{
+	/* both scalar by construction; said again for the register allocator */
+	val = (uint32_t)__builtin_amdgcn_readfirstlane((int)val);
+	l = (uint32_t)__builtin_amdgcn_readfirstlane((int)l);
+	asm volatile("s_mov_b32 m0, %2\n\ts_nop 0\n\tv_writelane_b32 %0, %1, m0"
+		     : "+v"(vec)
+		     : "s"(val), "s"(l)
+		     : "m0");
+	return vec;
+}
+
+/* 16 more bits of read-ahead; the window slides 32 bits late so that the
+ * cursor can step back by k (I_PCM, end position) without leaving it */
+__device__ __forceinline__ void cs_refill(CbEng &c, WaveBits &wb)
+{
+	if (__builtin_expect(c.k < 8u, 0)) {
+		if (__builtin_expect(wb.bitpos >= WB_SLIDE_BITS + 32u, 0)) {
+			wb.base += WB_SLIDE_BITS / 8u;
+			wb.bitpos -= WB_SLIDE_BITS;
+			wb_refill(wb);
+		}
+		uint32_t v = wb_peek(wb, 0);
+		wb_skip(wb, 16);
+		c.V = (c.V << 16) | (v >> 16);
+		c.k += 16u;
+	}
+}
+
+/* 9.3.1.2 at the cursor */
+__device__ __forceinline__ void cs_start(CbEng &c, WaveBits &wb, uint32_t lane)
+{
+	wb_sync(wb, lane);
+	c.V = wb_peek(wb, lane);
+	wb_skip(wb, 32);
+	c.k = 23;
+	c.range = 510;
+}
+
+/* RBSP bits the arithmetic decoder has consumed (what a bit-serial decoder
+ * would have read) */
+__device__ __forceinline__ uint32_t cs_pos(const CbEng &c, const WaveBits &wb)
+{
+	return wb_pos(wb) - c.k;
+}
+
+/* a read went past the end of the NAL: the oracle's reader fails there */
+__device__ __forceinline__ bool cs_eof(const CbEng &c, const WaveBits &wb)
+{
+	return wb_all_in(wb) && cs_pos(c, wb) > wb_total_bits(wb);
+}
+
+/* 9.3.3.2.1 DecodeDecision on the context in lane `slot` of `reg` */
+__device__ __forceinline__ uint32_t cs_dec(CbEng &c, WaveBits &wb, uint32_t &reg,
+					   uint32_t slot)
+{
+	cs_refill(c, wb);
+	const uint32_t s = cs_rl(reg, slot);
+	const uint32_t idx = s & 63u;
+	const uint32_t l4 = cs_rl(c.lps4, idx), tr = cs_rl(c.trans, idx);
+	const uint32_t rl = (l4 >> ((c.range >> 3) & 24u)) & 0xffu;
+	const uint32_t rm = c.range - rl;
+	const uint32_t T = rm << c.k;
+	const bool lps = c.V >= T;
+	c.V -= lps ? T : 0u;
+	c.range = lps ? rl : rm;
+	const uint32_t ns = (lps ? (tr & 0xffu) : (tr >> 8)) ^ (s & 64u);
+	reg = cs_wl(reg, ns, slot);
+	const uint32_t n = (uint32_t)__builtin_clz(c.range) - 23u;
+	c.range <<= n;
+	c.k -= n;
+	c.bins++;
+	return (s >> 6) ^ (lps ? 1u : 0u);
+}
+
+/* 9.3.3.2.3 DecodeBypass */
+__device__ __forceinline__ uint32_t cs_bypass(CbEng &c, WaveBits &wb)
+{
+	cs_refill(c, wb);
+	c.k -= 1u;
+	const uint32_t T = c.range << c.k;
+	const bool b = c.V >= T;
+	c.V -= b ? T : 0u;
+	c.bins++;
+	return b ? 1u : 0u;
+}
+
+/* 9.3.3.2.2.3 DecodeTerminate */
+__device__ __forceinline__ uint32_t cs_term(CbEng &c, WaveBits &wb)
+{
+	cs_refill(c, wb);
+	c.range -= 2u;
+	c.bins++;
+	if (c.V >= (c.range << c.k))
+		return 1;
+	const uint32_t n = (uint32_t)__builtin_clz(c.range) - 23u;
+	c.range <<= n;
+	c.k -= n;
+	return 0;
+}
+
+/* suffix of UEGk (9.3.2.3); ok cleared after 24 prefix bits */
+__device__ __forceinline__ uint32_t cs_egk(CbEng &c, WaveBits &wb, uint32_t k,
+					   bool &ok)
+{
+	uint32_t v = 0, n = 0;
+	while (cs_bypass(c, wb)) {
+		v += 1u << k;
+		k++;
+		if (++n >= 24u) {
+			ok = false;
+			return 0;
+		}
+	}
+	while (k--)
+		v += cs_bypass(c, wb) << k;
+	return v;
+}
+
+/* ---- context registers -------------------------------------------------------- */
+struct CbCtx {
+	uint32_t mb0, mb1;
+	uint32_t sig[3], last[3], abs[3], m8[3];
+};
+
+__device__ __forceinline__ void cs_rot3(uint32_t (&r)[3])
+{
+	uint32_t t = r[0];
+	r[0] = r[1];
+	r[1] = r[2];
+	r[2] = t;
+}
+
+/* ---- per-lane roles in the neighbour grids ---------------------------------- */
+#define CS_ROLE_TOP 1u /* border: the macroblock above */
+#define CS_ROLE_LEFT 2u /* border: the macroblock to the left */
+#define CS_ROLE_BOT 4u /* bottom row of the current macroblock */
+#define CS_ROLE_IN 8u /* a block of the current macroblock */
+
+struct CbLanes {
+	/* coded_block_flag grid, register 0: luma 5x5 at lanes 0..24; without
+	 * 4:4:4 the chroma AC grids (3 wide) at 25.. (Cb) and 40.. (Cr) */
+	uint32_t g_role, g_off, g_src;
+	/* list registers: |mvd x| 5x5 at 0..24, |mvd y| at 25..49, ref_idx 3x3
+	 * at 50..58 */
+	uint32_t l_role, l_off, l_src;
+	int32_t l_x, l_y; /* block coordinates of the lane, -1 on a border */
+	uint32_t l_kind; /* 0 mvd x, 1 mvd y, 2 ref_idx, 3 nothing */
+};
+
+__device__ __forceinline__ void cs_lane_roles(CbLanes &L, uint32_t lane, uint32_t cat)
+{
+	L.g_role = 0;
+	L.g_off = 0;
+	L.g_src = lane;
+	if (lane < 25u) {
+		const uint32_t gy = lane / 5u, gx = lane % 5u;
+		if (gy == 0 && gx >= 1) {
+			L.g_role = CS_ROLE_TOP;
+			L.g_off = 4u + gx - 1u;
+		} else if (gx == 0 && gy >= 1) {
+			L.g_role = CS_ROLE_LEFT;
+			L.g_src = lane + 4u;
+		} else if (gx >= 1 && gy >= 1) {
+			L.g_role = CS_ROLE_IN | (gy == 4 ? CS_ROLE_BOT : 0u);
+			L.g_off = 4u + gx - 1u;
+		}
+	} else if (lane < 55u && (cat == 1 || cat == 2)) {
+		const uint32_t c = (lane - 25u) / 15u, l2 = (lane - 25u) % 15u;
+		const uint32_t gy = l2 / 3u, gx = l2 % 3u, h = cat == 1 ? 2u : 4u;
+		if (gy == 0 && gx >= 1) {
+			L.g_role = CS_ROLE_TOP;
+			L.g_off = 8u + 2u * c + gx - 1u;
+		} else if (gx == 0 && gy >= 1 && gy <= h) {
+			L.g_role = CS_ROLE_LEFT;
+			L.g_src = lane + 2u;
+		} else if (gx >= 1 && gy >= 1 && gy <= h) {
+			L.g_role = CS_ROLE_IN | (gy == h ? CS_ROLE_BOT : 0u);
+			L.g_off = 8u + 2u * c + gx - 1u;
+		}
+	}
+	L.l_role = 0;
+	L.l_off = 0;
+	L.l_src = lane;
+	L.l_x = L.l_y = -1;
+	L.l_kind = 3;
+	if (lane < 50u) {
+		const uint32_t k = lane / 25u, l2 = lane % 25u;
+		const uint32_t gy = l2 / 5u, gx = l2 % 5u;
+		L.l_kind = k;
+		if (gy == 0 && gx >= 1) {
+			L.l_role = CS_ROLE_TOP;
+			L.l_off = 16u + 4u * k + gx - 1u;
+		} else if (gx == 0 && gy >= 1) {
+			L.l_role = CS_ROLE_LEFT;
+			L.l_src = lane + 4u;
+		} else if (gx >= 1 && gy >= 1) {
+			L.l_role = CS_ROLE_IN | (gy == 4 ? CS_ROLE_BOT : 0u);
+			L.l_off = 16u + 4u * k + gx - 1u;
+			L.l_x = (int32_t)gx - 1;
+			L.l_y = (int32_t)gy - 1;
+		}
+	} else if (lane < 59u) {
+		const uint32_t l2 = lane - 50u, gy = l2 / 3u, gx = l2 % 3u;
+		L.l_kind = 2;
+		if (gy == 0 && gx >= 1) {
+			L.l_role = CS_ROLE_TOP;
+			L.l_off = 24u + gx - 1u;
+		} else if (gx == 0 && gy >= 1) {
+			L.l_role = CS_ROLE_LEFT;
+			L.l_src = lane + 2u;
+		} else if (gx >= 1 && gy >= 1) {
+			L.l_role = CS_ROLE_IN | (gy == 2 ? CS_ROLE_BOT : 0u);
+			L.l_off = 24u + gx - 1u;
+			L.l_x = (int32_t)gx - 1;
+			L.l_y = (int32_t)gy - 1;
+		}
+	}
+}
+
+/* lane of a grid cell; x, y may be -1 */
+__device__ __forceinline__ uint32_t cs_g5(uint32_t x, uint32_t y)
+{
+	return (y + 1u) * 5u + x + 1u;
+}
+
+/* the border of a grid register for a new macroblock: the upper macroblock's
+ * bottom row from the row context, the left macroblock's right column out of
+ * the previous register; the inside starts as zeros.  fill: value of a border
+ * cell whose macroblock is not available */
+__device__ __forceinline__ uint32_t cs_grid_open(uint32_t prev, uint32_t role,
+						 uint32_t off, uint32_t src,
+						 const uint8_t *rowent, bool availA,
+						 bool availB, uint32_t fill)
+{
+	uint32_t top = rowent[off];
+	uint32_t left = (uint32_t)__shfl((int)prev, (int)src);
+	uint32_t v = 0;
+	v = (role & CS_ROLE_TOP) ? (availB ? top : fill) : v;
+	v = (role & CS_ROLE_LEFT) ? (availA ? left : fill) : v;
+	return v;
+}
+
+/* ---- the state of one slice --------------------------------------------------- */
+struct CbSlice {
+	uint32_t type, cat, W, field, t8mode, direct8x8, bdl, bdc, pcm_chroma;
+	uint32_t nref0, nref1;
+	uint32_t is_b, is_i, is_si;
+};
+
+/* ---- residual_block_cabac (7.3.5.3.3) ------------------------------------------
+ * IS8: an 8x8 block (contexts by Table 9-43, all in the M8 register);
+ * CDC: chroma DC (ctxIdxInc = Min(levelListIdx / NumC8x8, 2)).
+ * sreg / lreg / areg: the registers with this block's significant_coeff_flag,
+ * last_significant_coeff_flag and coeff_abs_level_minus1 contexts, s_off /
+ * a_off the first lane of its category.  Returns the coefficients as a per-lane
+ * value (lane = scanning position), 16 bits each. */
+template <bool IS8, bool CDC>
+__device__ __forceinline__ uint32_t
+cs_block(CbEng &c, WaveBits &wb, uint32_t &sreg, uint32_t &lreg, uint32_t &areg,
+	 uint32_t s_off, uint32_t a_off, uint32_t numc, uint32_t nc8, bool &ok)
+{
+	uint64_t sig = 0;
+	uint32_t i = 0;
+	bool last = false;
+	for (; i + 1u < numc; i++) {
+		uint32_t si, li;
+		if (IS8) {
+			const uint32_t p = cs_rl(c.pos8, i);
+			si = CXL_SIG8 + (p & 0xffu);
+			li = CXL_LAST8 + (p >> 8);
+		} else if (CDC) {
+			const uint32_t q = i / nc8;
+			si = li = s_off + (q < 2u ? q : 2u);
+		} else {
+			si = li = s_off + i;
+		}
+		if (cs_dec(c, wb, sreg, si)) {
+			sig |= 1ull << i;
+			if (cs_dec(c, wb, lreg, li)) {
+				last = true;
+				break;
+			}
+		}
+	}
+	if (!last)
+		sig |= 1ull << (numc - 1u);
+	uint32_t coef = 0, eq1 = 0, gt1 = 0;
+	while (sig) {
+		const uint32_t p = 63u - (uint32_t)__builtin_clzll(sig);
+		sig &= ~(1ull << p);
+		uint32_t a = 0;
+		if (cs_dec(c, wb, areg,
+			   a_off + (gt1 ? 0u : (eq1 < 3u ? 1u + eq1 : 4u)))) {
+			const uint32_t lim = CDC ? 3u : 4u;
+			const uint32_t cn = a_off + 5u + (gt1 < lim ? gt1 : lim);
+			a = 1;
+			while (a < 14u && cs_dec(c, wb, areg, cn))
+				a++;
+			if (a == 14u)
+				a += cs_egk(c, wb, 0, ok);
+			gt1++;
+		} else {
+			eq1++;
+		}
+		const uint32_t sgn = cs_bypass(c, wb);
+		const uint32_t v = a + 1u;
+		coef = cs_wl(coef, (sgn ? 0u - v : v) & 0xffffu, p);
+	}
+	return coef;
+}
+
+/* the slice data of one CABAC slice; returns the status */
+__device__ __forceinline__ int
+cs_slice_data(CbEng &c, WaveBits &wb, CbCtx &x, uint8_t *stage, uint8_t *row,
+	      OutCtx &o, uint32_t lane, const CbSlice &S, uint32_t first_mb,
+	      uint32_t mb_capacity, uint32_t &mb_count, uint32_t prio_slot,
+	      uint32_t prio_on)
+{
+	/* cabac_alignment_one_bit */
+	{
+		uint32_t p = wb_pos(wb) & 7u;
+		if (p) {
+			if (wb_all_in(wb) && wb_pos(wb) + 8u - p > wb_total_bits(wb))
+				return -EIO;
+			if (wb_u(wb, lane, 8u - p) != (1u << (8u - p)) - 1u)
+				return -EIO;
+		}
+	}
+	cs_start(c, wb, lane);
+	if (cs_eof(c, wb))
+		return -EIO;
+
+	CbLanes LN;
+	cs_lane_roles(LN, lane, S.cat);
+	const bool c12 = S.cat == 1 || S.cat == 2;
+	const bool c444 = S.cat == 3;
+	const uint32_t nc8 = S.cat == 2 ? 2u : 1u; /* NumC8x8 */
+	const uint32_t nchroma = 4u * nc8; /* chroma blocks per component */
+	const uint32_t field_flag = S.field ? (uint32_t)H264_AMD_MB_FIELD : 0u;
+	const uint32_t skip_word0 =
+		(S.is_b ? (uint32_t)H264_MB_TYPE_B_SKIP : (uint32_t)H264_MB_TYPE_P_SKIP) |
+		(((uint32_t)H264_AMD_MB_SKIPPED | field_flag) << 16);
+	const uint32_t skip_ctx = S.is_b ? 24u : 11u;
+
+	uint32_t mbx = first_mb % S.W, mbidx = 0;
+	uint32_t left = 0; /* row word 0 of the previous macroblock */
+	uint32_t prev_qpd_nz = 0;
+	/* neighbour grids of the previous macroblock (left borders come out of
+	 * them): coded_block_flag per component, the two lists */
+	uint32_t G[3] = {0, 0, 0}, LL[2] = {0, 0};
+
+	for (;;) {
+		if (mbidx >= mb_capacity)
+			return H264_AMD_E_MB_OVERFLOW;
+		if (prio_on && (mbidx & 63u) == 0u) {
+			switch (((mbidx >> 6) + prio_slot) & 3u) {
+			case 0:
+				__builtin_amdgcn_s_setprio(0);
+				break;
+			case 1:
+				__builtin_amdgcn_s_setprio(1);
+				break;
+			case 2:
+				__builtin_amdgcn_s_setprio(2);
+				break;
+			default:
+				__builtin_amdgcn_s_setprio(3);
+				break;
+			}
+		}
+		/* neighbours inside the slice (6.4.9; ref src/h264_macroblock.c:306-351
+		 * for the same rule) */
+		uint8_t *rowent = row + CS_ROW_STRIDE * mbx;
+		const bool availA = mbx != 0 && mbidx >= 1;
+		const bool availB = mbidx >= S.W;
+		const uint32_t nbA = availA ? left : 0u;
+		const uint32_t nbB =
+			availB ? wb_uniform(*reinterpret_cast<const uint32_t *>(rowent)) : 0u;
+		const uint32_t vA = nbA >> 7 & 1u, vB = nbB >> 7 & 1u;
+		uint32_t me = CS_NB_VALID;
+		uint32_t skip = 0;
+
+		if (!S.is_i) {
+			/* mb_skip_flag: neighbour available and not skipped */
+			skip = cs_dec(c, wb, x.mb0,
+				      skip_ctx + (vA & ~nbA) + (vB & ~nbB));
+		}
+		if (skip) {
+			if (cs_eof(c, wb))
+				return -EIO;
+			sd_emit_skipped(o, skip_word0, mbidx, lane);
+			me |= CS_NB_SKIP | (S.is_b ? CS_NB_BDIR : 0u);
+			prev_qpd_nz = 0;
+			G[0] = G[1] = G[2] = 0;
+			LL[0] = LL[1] = 0;
+		} else {
+			/* ---- macroblock_layer (7.3.5) ---- */
+			uint32_t raw = 0; /* mb_type as Tables 7-11 / 7-13 / 7-14 number it */
+			uint32_t it = 0xffu; /* I slice numbering of an intra type */
+			{
+				/* the bin string of the intra types at ctxIdxOffset
+				 * 3 / 17 / 32; c0: context of its first bin */
+				uint32_t off = 3, c0 = 0;
+				bool intra = true;
+				if (S.is_i && !S.is_si) {
+					c0 = 3u + (vA & ~(nbA >> 4)) + (vB & ~(nbB >> 4));
+				} else if (S.is_si) {
+					if (cs_dec(c, wb, x.mb0,
+						   0u + (vA & ~(nbA >> 5)) + (vB & ~(nbB >> 5)))) {
+						c0 = 3u + (vA & ~(nbA >> 4)) +
+						     (vB & ~(nbB >> 4));
+						raw = 1;
+					} else {
+						intra = false; /* mb_type SI: raw 0 */
+						it = 0xfeu;
+					}
+				} else if (!S.is_b) {
+					if (cs_dec(c, wb, x.mb0, 14)) {
+						off = c0 = 17;
+						raw = 5;
+					} else {
+						intra = false;
+						if (!cs_dec(c, wb, x.mb0, 15))
+							raw = cs_dec(c, wb, x.mb0, 16) ? 3u : 0u;
+						else
+							raw = cs_dec(c, wb, x.mb0, 17) ? 1u : 2u;
+					}
+				} else {
+					intra = false;
+					if (!cs_dec(c, wb, x.mb0,
+						    27u + (vA & ~(nbA >> 6)) +
+							    (vB & ~(nbB >> 6)))) {
+						raw = 0;
+					} else if (!cs_dec(c, wb, x.mb0, 27 + 3)) {
+						raw = 1u + cs_dec(c, wb, x.mb0, 27 + 5);
+					} else {
+						uint32_t bits = cs_dec(c, wb, x.mb0, 27 + 4) << 3;
+						bits |= cs_dec(c, wb, x.mb0, 27 + 5) << 2;
+						bits |= cs_dec(c, wb, x.mb0, 27 + 5) << 1;
+						bits |= cs_dec(c, wb, x.mb0, 27 + 5);
+						if (bits < 8u) {
+							raw = 3u + bits;
+						} else if (bits == 13u) {
+							intra = true;
+							off = c0 = 32;
+							raw = 23;
+						} else if (bits == 14u) {
+							raw = 11;
+						} else if (bits == 15u) {
+							raw = 22;
+						} else {
+							raw = 2u * bits +
+							      cs_dec(c, wb, x.mb0, 27 + 5) - 4u;
+						}
+					}
+				}
+				if (intra) {
+					const bool i3 = off == 3;
+					if (!cs_dec(c, wb, x.mb0, c0)) {
+						it = 0;
+					} else if (cs_term(c, wb)) {
+						it = 25;
+					} else {
+						uint32_t luma = cs_dec(c, wb, x.mb0,
+								       i3 ? 3u + 3u : off + 1u);
+						uint32_t chroma = cs_dec(c, wb, x.mb0,
+									 i3 ? 3u + 4u : off + 2u);
+						if (chroma)
+							chroma += cs_dec(c, wb, x.mb0,
+									 i3 ? 3u + 5u : off + 2u);
+						uint32_t pred = cs_dec(c, wb, x.mb0,
+								       i3 ? 3u + 6u : off + 3u)
+								<< 1;
+						pred |= cs_dec(c, wb, x.mb0,
+							       i3 ? 3u + 7u : off + 3u);
+						it = 1u + pred + 4u * chroma + 12u * luma;
+					}
+					raw += it;
+				}
+			}
+
+			/* the record's head: dword j in lane j */
+			uint32_t H = 0;
+			uint32_t mb_type, cbp_luma = 0, cbp_chroma = 0, t8 = 0;
+			uint32_t flags = field_flag, icp = 0, i16pred = 0;
+			int32_t qpd = 0;
+			const bool is_intra = it != 0xffu;
+			bool i16 = false;
+			bool ok = true;
+
+			if (it == 25u) {
+				/* ---- I_PCM: the terminating bin ended the arithmetic
+				 * codeword; pcm_alignment_zero_bit, the samples, and a
+				 * fresh start of the decoding engine (9.3.1.2) ---- */
+				if (cs_eof(c, wb))
+					return -EIO;
+				wb.bitpos -= c.k; /* hand the read-ahead back */
+				uint32_t p = wb_pos(wb) & 7u;
+				if (p) {
+					if (wb_all_in(wb) &&
+					    wb_pos(wb) + 8u - p > wb_total_bits(wb))
+						return -EIO;
+					if (wb_u(wb, lane, 8u - p) != 0)
+						return -EIO;
+				}
+				const uint32_t total = 256u + 2u * S.pcm_chroma;
+				for (uint32_t part = 0; part < CS_STAGE_BYTES / 1024u; part++)
+					*reinterpret_cast<uint4 *>(stage + part * 1024u +
+								   16u * lane) =
+						make_uint4(0, 0, 0, 0);
+				for (uint32_t k0 = 0; k0 < total; k0 += 64u) {
+					wb_sync(wb, lane);
+					if (wb_overrun(wb))
+						return -EIO;
+					const uint32_t bd = k0 < 256u ? S.bdl : S.bdc;
+					uint32_t off = wb.bitpos + lane * bd;
+					uint32_t hi = (uint32_t)__shfl((int)wb.wreg,
+								       (int)(off >> 5));
+					uint32_t lo = (uint32_t)__shfl(
+						(int)wb.wreg, (int)((off >> 5) + 1u));
+					uint64_t v = (((uint64_t)hi << 32) | lo)
+						     << (off & 31u);
+					uint32_t smp = (uint32_t)(v >> 32) >> (32u - bd);
+					*reinterpret_cast<uint16_t *>(
+						stage + H264_AMD_T2_HEAD + 2u * (k0 + lane)) =
+						(uint16_t)smp;
+					wb_skip(wb, 64u * bd);
+				}
+				wb_sync(wb, lane);
+				if (wb_overrun(wb))
+					return -EIO;
+				cs_start(c, wb, lane);
+				mb_type = H264_MB_TYPE_I_PCM;
+				H = lane == 0 ? (mb_type | (flags << 16) | (raw << 24))
+				    : lane >= 4 && lane < 16 ? 0x10101010u
+							     : 0u;
+				me |= CS_NB_PCM | (0x2fu << 8) | (7u << 16);
+				prev_qpd_nz = 0;
+				G[0] = G[1] = G[2] = 1;
+				LL[0] = LL[1] = 0;
+			} else {
+				/* ---- derived macroblock variables ---- */
+				uint32_t nparts = 1, use[4] = {0, 0, 0, 0};
+				uint32_t shape[4] = {0, 0, 0, 0}; /* sub-mb partition shape */
+				uint32_t pshape = 0; /* 0 16x16, 1 16x8, 2 8x16, 3 8x8 */
+				bool direct16 = false;
+				if (is_intra) {
+					if (it == 0xfeu) {
+						mb_type = H264_MB_TYPE_SI;
+					} else if (it == 0) {
+						mb_type = H264_MB_TYPE_I_NxN;
+						me |= CS_NB_INXN;
+					} else {
+						mb_type = H264_MB_TYPE_I_16x16;
+						i16 = true;
+						i16pred = (it - 1u) & 3u;
+						cbp_chroma = ((it - 1u) >> 2) % 3u;
+						cbp_luma = it <= 12u ? 0u : 15u;
+					}
+					if (mb_type == H264_MB_TYPE_SI)
+						me |= CS_NB_SI;
+				} else if (!S.is_b) {
+					mb_type = H264_MB_TYPE_P_16x16 + raw;
+					pshape = raw;
+					nparts = raw == 0 ? 1u : raw == 3 ? 4u : 2u;
+					use[0] = use[1] = use[2] = use[3] = 1;
+				} else if (raw == 0) {
+					mb_type = H264_MB_TYPE_B_Direct_16x16;
+					direct16 = true;
+					me |= CS_NB_BDIR;
+				} else if (raw <= 3u) {
+					mb_type = H264_MB_TYPE_B_16x16;
+					use[0] = raw;
+				} else if (raw <= 21u) {
+					const uint32_t e = (raw - 4u) >> 1;
+					mb_type = (raw & 1u) ? H264_MB_TYPE_B_8x16
+							     : H264_MB_TYPE_B_16x8;
+					pshape = (raw & 1u) ? 2u : 1u;
+					nparts = 2;
+					/* Table 7-14: L0 = 1, L1 = 2, Bi = 3 */
+					use[0] = (0x3f999u >> (2u * e)) & 3u;
+					use[1] = (0x39f69u >> (2u * e)) & 3u;
+				} else {
+					mb_type = H264_MB_TYPE_B_8x8;
+					pshape = 3;
+					nparts = 4;
+				}
+
+				bool no_sub8 = true;
+				uint32_t pred_lo = 0, pred_hi = 0, refw0 = 0, refw1 = 0;
+				if (!is_intra) {
+					/* grids of |mvd| and ref_idx */
+#pragma unroll
+					for (uint32_t l = 0; l < 2; l++)
+						LL[l] = cs_grid_open(
+							LL[l], LN.l_role, LN.l_off + 12u * l,
+							LN.l_src, rowent, vA != 0, vB != 0, 0);
+				} else {
+					LL[0] = LL[1] = 0;
+				}
+
+				if (!is_intra && nparts == 4) {
+					/* ---- sub_mb_pred (7.3.5.2) ---- */
+#pragma unroll
+					for (uint32_t p = 0; p < 4; p++) {
+						uint32_t st;
+						if (!S.is_b) {
+							if (cs_dec(c, wb, x.mb0, 21))
+								st = 0;
+							else if (!cs_dec(c, wb, x.mb0, 22))
+								st = 1;
+							else
+								st = cs_dec(c, wb, x.mb0, 23) ? 2u : 3u;
+							use[p] = 1;
+							shape[p] = st;
+						} else {
+							if (!cs_dec(c, wb, x.mb0, 36)) {
+								st = 0;
+							} else if (!cs_dec(c, wb, x.mb0, 37)) {
+								st = 1u + cs_dec(c, wb, x.mb0, 39);
+							} else {
+								st = 3;
+								bool done = false;
+								if (cs_dec(c, wb, x.mb0, 38)) {
+									if (cs_dec(c, wb, x.mb0, 39)) {
+										st = 11u +
+										     cs_dec(c, wb, x.mb0, 39);
+										done = true;
+									} else {
+										st += 4;
+									}
+								}
+								if (!done) {
+									st += 2u * cs_dec(c, wb, x.mb0, 39);
+									st += cs_dec(c, wb, x.mb0, 39);
+								}
+							}
+							/* Table 7-18 */
+							use[p] = st == 0   ? 0u
+								 : st <= 3 ? st
+								 : st <= 9 ? 1u + ((st - 4u) >> 1)
+									   : st - 9u;
+							shape[p] = st <= 3   ? 0u
+								   : st <= 9 ? 1u + (st & 1u)
+									     : 3u;
+						}
+						pred_lo |= st << (8u * p);
+						if (S.is_b && st == 0) {
+							if (!S.direct8x8)
+								no_sub8 = false;
+						} else if (shape[p] != 0) {
+							no_sub8 = false;
+						}
+					}
+				} else if (is_intra && !i16) {
+					/* transform_size_8x8_flag of I_NxN, then the
+					 * prediction modes */
+					if (S.t8mode && mb_type == H264_MB_TYPE_I_NxN) {
+						t8 = cs_dec(c, wb, x.mb1,
+							    CXL_T8 + (nbA >> 2 & 1u) +
+								    (nbB >> 2 & 1u));
+					}
+					const uint32_t n = t8 ? 4u : 16u;
+					for (uint32_t b = 0; b < n; b++) {
+						uint32_t nib = 0;
+						if (!cs_dec(c, wb, x.mb1, 68 - 64)) {
+							uint32_t v = cs_dec(c, wb, x.mb1, 69 - 64);
+							v |= cs_dec(c, wb, x.mb1, 69 - 64) << 1;
+							v |= cs_dec(c, wb, x.mb1, 69 - 64) << 2;
+							nib = v + 1u;
+						}
+						if (b < 8)
+							pred_lo |= nib << (4u * b);
+						else
+							pred_hi |= nib << (4u * (b - 8u));
+					}
+				}
+				if (is_intra && c12) {
+					/* intra_chroma_pred_mode */
+					icp = cs_dec(c, wb, x.mb1,
+						     64 - 64 + (nbA >> 1 & 1u) + (nbB >> 1 & 1u));
+					if (icp == 1)
+						icp += cs_dec(c, wb, x.mb1, 64 - 64 + 3);
+					if (icp == 2)
+						icp += cs_dec(c, wb, x.mb1, 64 - 64 + 3);
+					me |= icp ? CS_NB_ICPNZ : 0u;
+				}
+				if (!is_intra && !direct16) {
+					/* ---- ref_idx (9.3.3.1.1.6), then mvd (9.3.3.1.1.7)
+					 * of the partitions, list 0 before list 1 ---- */
+#pragma unroll
+					for (uint32_t l = 0; l < 2; l++) {
+						const uint32_t nref = l ? S.nref1 : S.nref0;
+						if (nref == 0)
+							continue;
+						uint32_t refw = 0;
+						for (uint32_t p = 0; p < nparts; p++) {
+							if (!(use[p] & (1u << l)))
+								continue;
+							uint32_t x8, y8, w8, h8;
+							if (pshape == 3) {
+								x8 = p & 1u;
+								y8 = p >> 1;
+								w8 = h8 = 1;
+							} else {
+								x8 = pshape == 2 ? p : 0u;
+								y8 = pshape == 1 ? p : 0u;
+								w8 = pshape == 2 ? 1u : 2u;
+								h8 = pshape == 1 ? 1u : 2u;
+							}
+							const uint32_t ra = cs_rl(
+								LL[l], 50u + (y8 + 1u) * 3u + x8);
+							const uint32_t rb = cs_rl(
+								LL[l], 50u + y8 * 3u + x8 + 1u);
+							uint32_t v = 0;
+							if (cs_dec(c, wb, x.mb0,
+								   54u + (ra > 0) + 2u * (rb > 0))) {
+								v = 1;
+								uint32_t b = cs_dec(c, wb, x.mb0, 54 + 4);
+								while (b) {
+									if (++v > 255u)
+										return -EIO;
+									b = cs_dec(c, wb, x.mb0, 54 + 5);
+								}
+							}
+							refw |= v << (8u * p);
+							const bool in =
+								LN.l_kind == 2 &&
+								(uint32_t)(LN.l_x - (int32_t)x8) < w8 &&
+								(uint32_t)(LN.l_y - (int32_t)y8) < h8;
+							LL[l] = in ? v : LL[l];
+						}
+						if (l)
+							refw1 = refw;
+						else
+							refw0 = refw;
+					}
+#pragma unroll
+					for (uint32_t l = 0; l < 2; l++) {
+						for (uint32_t p = 0; p < nparts; p++) {
+							if (!(use[p] & (1u << l)))
+								continue;
+							const uint32_t nsub =
+								pshape != 3	? 1u
+								: shape[p] == 0 ? 1u
+								: shape[p] == 3 ? 4u
+										: 2u;
+							for (uint32_t s = 0; s < nsub; s++) {
+								uint32_t x4, y4, w4, h4;
+								if (pshape != 3) {
+									x4 = pshape == 2 ? 2u * p : 0u;
+									y4 = pshape == 1 ? 2u * p : 0u;
+									w4 = pshape == 2 ? 2u : 4u;
+									h4 = pshape == 1 ? 2u : 4u;
+								} else {
+									const uint32_t sh = shape[p];
+									x4 = 2u * (p & 1u);
+									y4 = 2u * (p >> 1);
+									w4 = h4 = 2;
+									if (sh == 1) {
+										h4 = 1;
+										y4 += s;
+									} else if (sh == 2) {
+										w4 = 1;
+										x4 += s;
+									} else if (sh == 3) {
+										w4 = h4 = 1;
+										x4 += s & 1u;
+										y4 += s >> 1;
+									}
+								}
+								uint32_t mv[2];
+#pragma unroll
+								for (uint32_t k = 0; k < 2; k++) {
+									const uint32_t off = k ? 47u : 40u;
+									const uint32_t sum =
+										cs_rl(LL[l], 25u * k +
+												     cs_g5(x4 - 1u, y4)) +
+										cs_rl(LL[l], 25u * k +
+												     cs_g5(x4, y4 - 1u));
+									const uint32_t inc =
+										sum < 3u ? 0u : sum > 32u ? 2u : 1u;
+									uint32_t m = 0;
+									if (cs_dec(c, wb, x.mb0, off + inc)) {
+										m = 1;
+										while (m < 9u &&
+										       cs_dec(c, wb, x.mb0,
+											      off + (m < 4u ? m + 2u
+													    : 6u)))
+											m++;
+										if (m == 9u)
+											m += cs_egk(c, wb, 3, ok);
+									}
+									uint32_t sv = m;
+									if (m && cs_bypass(c, wb))
+										sv = 0u - m;
+									mv[k] = sv & 0xffffu;
+									const uint32_t am = m < 255u ? m : 255u;
+									const bool in =
+										LN.l_kind == k &&
+										(uint32_t)(LN.l_x - (int32_t)x4) < w4 &&
+										(uint32_t)(LN.l_y - (int32_t)y4) < h4;
+									LL[l] = in ? am : LL[l];
+								}
+								if (!ok)
+									return -EIO;
+								H = cs_wl(H, mv[0] | (mv[1] << 16),
+									  32u + 16u * l + 4u * p + s);
+							}
+						}
+					}
+				}
+
+				if (!i16) {
+					/* ---- coded_block_pattern (9.3.2.6, 9.3.3.1.1.4) ---- */
+					const uint32_t ca = nbA >> 8, cb = nbB >> 8;
+					/* a neighbouring 8x8 block without coefficients
+					 * counts; I_PCM keeps 0x2f, a skipped one 0 */
+					uint32_t b0 = cs_dec(c, wb, x.mb1,
+							     73 - 64 + (vA & ~(ca >> 1)) +
+								     2u * (vB & ~(cb >> 2)));
+					uint32_t b1 = cs_dec(c, wb, x.mb1,
+							     73 - 64 + (b0 ^ 1u) +
+								     2u * (vB & ~(cb >> 3)));
+					uint32_t b2 = cs_dec(c, wb, x.mb1,
+							     73 - 64 + (vA & ~(ca >> 3)) +
+								     2u * (b0 ^ 1u));
+					uint32_t b3 = cs_dec(c, wb, x.mb1,
+							     73 - 64 + (b2 ^ 1u) + 2u * (b1 ^ 1u));
+					cbp_luma = b0 | (b1 << 1) | (b2 << 2) | (b3 << 3);
+					if (c12) {
+						const uint32_t cca = (ca >> 4) & 3u,
+							       ccb = (cb >> 4) & 3u;
+						if (cs_dec(c, wb, x.mb1,
+							   77 - 64 + (cca != 0) + 2u * (ccb != 0)))
+							cbp_chroma =
+								1u + cs_dec(c, wb, x.mb1,
+									    77 - 64 + 4 + (cca == 2) +
+										    2u * (ccb == 2));
+					}
+					if (cbp_luma && S.t8mode &&
+					    mb_type != H264_MB_TYPE_I_NxN && no_sub8 &&
+					    (!direct16 || S.direct8x8))
+						t8 = cs_dec(c, wb, x.mb1,
+							    CXL_T8 + (nbA >> 2 & 1u) +
+								    (nbB >> 2 & 1u));
+				}
+				const uint32_t cbp = cbp_luma | (cbp_chroma << 4);
+				me |= (cbp << 8) | (t8 ? CS_NB_T8 : 0u);
+				flags |= t8 ? (uint32_t)H264_AMD_MB_TRANSFORM_8X8 : 0u;
+
+				/* record: coefficient area zeroed, head kept in H */
+				for (uint32_t part = 0; part < CS_STAGE_BYTES / 1024u; part++)
+					*reinterpret_cast<uint4 *>(stage + part * 1024u +
+								   16u * lane) =
+						make_uint4(0, 0, 0, 0);
+				uint32_t NZ = 0; /* lane b: nz_coeff[b] */
+				uint32_t dc = 0;
+
+				if (cbp || i16) {
+					/* ---- mb_qp_delta (9.3.2.7, 9.3.3.1.1.5) ---- */
+					uint32_t k = 0;
+					if (cs_dec(c, wb, x.mb0, 60u + prev_qpd_nz)) {
+						k = 1;
+						uint32_t b = cs_dec(c, wb, x.mb0, 60 + 2);
+						while (b) {
+							if (++k > 255u)
+								return -EIO;
+							b = cs_dec(c, wb, x.mb0, 60 + 3);
+						}
+					}
+					qpd = (k & 1u) ? (int32_t)((k + 1u) / 2u)
+						       : -(int32_t)(k / 2u);
+					prev_qpd_nz = k != 0 ? 1u : 0u;
+
+					/* ---- residual (7.3.5.3) ---- */
+					const uint32_t fill = is_intra ? 1u : 0u;
+					const uint32_t ncomp = c444 ? 3u : 1u;
+					/* grids: borders now that "intra" is known */
+#pragma unroll
+					for (uint32_t q = 0; q < 3; q++) {
+						if (q >= ncomp)
+							continue;
+						G[q] = cs_grid_open(G[q], LN.g_role,
+								    LN.g_off + 4u * q, LN.g_src,
+								    rowent, vA != 0, vB != 0, fill);
+					}
+					/* an 8x8 block coded with its own flag (4:4:4) only
+					 * counts a neighbouring MACROBLOCK that was
+					 * transformed 8x8 (or is I_PCM) */
+					if (c444 && t8) {
+						const bool okA = !vA || (nbA & (CS_NB_T8 | CS_NB_PCM));
+						const bool okB = !vB || (nbB & (CS_NB_T8 | CS_NB_PCM));
+#pragma unroll
+						for (uint32_t q = 0; q < 3; q++) {
+							G[q] = (LN.g_role & CS_ROLE_LEFT) && !okA ? 0u : G[q];
+							G[q] = (LN.g_role & CS_ROLE_TOP) && !okB ? 0u : G[q];
+						}
+					}
+					for (uint32_t comp = 0; comp < ncomp; comp++) {
+						const uint32_t cbase = 256u * comp;
+						if (i16) {
+							/* Intra16x16DCLevel */
+							const uint32_t dA =
+								vA ? (nbA >> (16u + comp)) & 1u : fill;
+							const uint32_t dB =
+								vB ? (nbB >> (16u + comp)) & 1u : fill;
+							if (cs_dec(c, wb, x.m8[0],
+								   CXL_CBF + 0u + dA + 2u * dB)) {
+								uint32_t cf = cs_block<false, false>(
+									c, wb, x.sig[0], x.last[0],
+									x.abs[0], 0, 0, 16, 1, ok);
+								if (lane < 16u)
+									*reinterpret_cast<uint16_t *>(
+										stage + H264_AMD_T2_HEAD +
+										2u * (cbase + lane)) =
+										(uint16_t)cf;
+								dc |= 1u << comp;
+							}
+						}
+						if (t8) {
+							for (uint32_t b8 = 0; b8 < 4; b8++) {
+								if (!((cbp_luma >> b8) & 1u))
+									continue;
+								const uint32_t x4 = 2u * (b8 & 1u),
+									       y4 = 2u * (b8 >> 1);
+								uint32_t coded = 1;
+								if (c444)
+									coded = cs_dec(
+										c, wb, x.m8[0],
+										CXL_CBF8 +
+											cs_rl(G[0], cs_g5(x4 - 1u, y4)) +
+											2u * cs_rl(G[0], cs_g5(x4, y4 - 1u)));
+								if (!coded)
+									continue;
+								uint32_t cf = cs_block<true, false>(
+									c, wb, x.m8[0], x.m8[0], x.abs[0],
+									0, CXL_ABS8, 64, 1, ok);
+								/* 4x4 view of the record: coefficient
+								 * 4 k + j is coefficient k of array j */
+								*reinterpret_cast<uint16_t *>(
+									stage + H264_AMD_T2_HEAD +
+									2u * (cbase + 16u * (4u * b8 + (lane & 3u)) +
+									      (lane >> 2))) = (uint16_t)cf;
+								const uint64_t nzm =
+									__builtin_amdgcn_ballot_w64((cf & 0xffffu) != 0);
+#pragma unroll
+								for (uint32_t j = 0; j < 4; j++)
+									NZ = cs_wl(NZ,
+										   (uint32_t)__builtin_popcountll(
+											   nzm & (0x1111111111111111ull << j)),
+										   16u * comp + 4u * b8 + j);
+								const uint32_t gl = cs_g5(x4, y4);
+								G[0] = (lane == gl || lane == gl + 1u ||
+									lane == gl + 5u || lane == gl + 6u)
+									       ? 1u
+									       : G[0];
+							}
+						} else {
+							for (uint32_t b = 0; b < 16; b++) {
+								if (!((cbp_luma >> (b >> 2)) & 1u))
+									continue;
+								/* 6.4.3: position of luma4x4BlkIdx b */
+								const uint32_t x4 = (b & 1u) | ((b >> 1) & 2u);
+								const uint32_t y4 = ((b >> 1) & 1u) | ((b >> 2) & 2u);
+								const uint32_t inc =
+									cs_rl(G[0], cs_g5(x4 - 1u, y4)) +
+									2u * cs_rl(G[0], cs_g5(x4, y4 - 1u));
+								if (!cs_dec(c, wb, x.m8[0],
+									    CXL_CBF + (i16 ? 4u : 8u) + inc))
+									continue;
+								uint32_t cf;
+								if (i16)
+									cf = cs_block<false, false>(
+										c, wb, x.sig[0], x.last[0],
+										x.abs[0], 15, 10, 15, 1, ok);
+								else
+									cf = cs_block<false, false>(
+										c, wb, x.sig[0], x.last[0],
+										x.abs[0], 29, 20, 16, 1, ok);
+								const uint32_t numc = i16 ? 15u : 16u;
+								if (lane < numc)
+									*reinterpret_cast<uint16_t *>(
+										stage + H264_AMD_T2_HEAD +
+										2u * (cbase +
+										      (i16 ? 16u + 15u * b : 16u * b) +
+										      lane)) = (uint16_t)cf;
+								NZ = cs_wl(NZ,
+									   (uint32_t)__builtin_popcountll(
+										   __builtin_amdgcn_ballot_w64(
+											   (cf & 0xffffu) != 0)),
+									   16u * comp + b);
+								G[0] = lane == cs_g5(x4, y4) ? 1u : G[0];
+							}
+						}
+						if (c444) {
+							/* next component: its contexts and its
+							 * grid move to position 0 */
+							cs_rot3(x.sig);
+							cs_rot3(x.last);
+							cs_rot3(x.abs);
+							cs_rot3(x.m8);
+							cs_rot3(G);
+						}
+					}
+					if (c12) {
+						if (cbp_chroma & 3u) {
+#pragma unroll
+							for (uint32_t cc = 0; cc < 2; cc++) {
+								const uint32_t dA =
+									vA ? (nbA >> (17u + cc)) & 1u : fill;
+								const uint32_t dB =
+									vB ? (nbB >> (17u + cc)) & 1u : fill;
+								if (!cs_dec(c, wb, x.mb1,
+									    97 - 64 + dA + 2u * dB))
+									continue;
+								uint32_t cf = cs_block<false, true>(
+									c, wb, x.sig[0], x.last[0],
+									x.abs[0], 44, 30, nchroma, nc8, ok);
+								if (lane < nchroma)
+									*reinterpret_cast<uint16_t *>(
+										stage + H264_AMD_T2_HEAD +
+										2u * (256u + nchroma * cc + lane)) =
+										(uint16_t)cf;
+								dc |= 2u << cc;
+							}
+						}
+						if (cbp_chroma & 2u) {
+#pragma unroll
+							for (uint32_t cc = 0; cc < 2; cc++) {
+								for (uint32_t b = 0; b < nchroma; b++) {
+									const uint32_t gl =
+										25u + 15u * cc +
+										((b >> 1) + 1u) * 3u + (b & 1u) + 1u;
+									const uint32_t inc =
+										cs_rl(G[0], gl - 1u) +
+										2u * cs_rl(G[0], gl - 3u);
+									if (!cs_dec(c, wb, x.mb1,
+										    101 - 64 + inc))
+										continue;
+									uint32_t cf = cs_block<false, false>(
+										c, wb, x.sig[0], x.last[0],
+										x.abs[0], 47, 39, 15, 1, ok);
+									if (lane < 15u)
+										*reinterpret_cast<uint16_t *>(
+											stage + H264_AMD_T2_HEAD +
+											2u * (256u + 2u * nchroma +
+											      15u * (nchroma * cc + b) +
+											      lane)) = (uint16_t)cf;
+									NZ = cs_wl(
+										NZ,
+										(uint32_t)__builtin_popcountll(
+											__builtin_amdgcn_ballot_w64(
+												(cf & 0xffffu) != 0)),
+										16u * (1u + cc) + b);
+									G[0] = lane == gl ? 1u : G[0];
+								}
+							}
+						}
+					}
+					if (!ok)
+						return -EIO;
+					/* only the inside of a grid travels on */
+#pragma unroll
+					for (uint32_t q = 0; q < 3; q++)
+						G[q] = (LN.g_role & CS_ROLE_IN) && q < ncomp ? G[q] : 0u;
+				} else {
+					prev_qpd_nz = 0;
+					G[0] = G[1] = G[2] = 0;
+				}
+				me |= dc << 16;
+
+				/* ---- the record ---- */
+				H = lane == 0 ? (mb_type | (cbp << 8) | (flags << 16) |
+						 (raw << 24))
+				    : lane == 1
+					    ? (((uint32_t)qpd & 0xffffu) | (icp << 16) |
+					       (i16pred << 24))
+				    : lane == 2	 ? pred_lo
+				    : lane == 3	 ? pred_hi
+				    : lane == 16 ? refw0
+				    : lane == 17 ? refw1
+						 : H;
+				/* nz_coeff: four counts per dword */
+				{
+					const uint32_t q = 4u * (lane & 15u);
+					uint32_t n0 = (uint32_t)__shfl((int)NZ, (int)q);
+					uint32_t n1 = (uint32_t)__shfl((int)NZ, (int)(q + 1u));
+					uint32_t n2 = (uint32_t)__shfl((int)NZ, (int)(q + 2u));
+					uint32_t n3 = (uint32_t)__shfl((int)NZ, (int)(q + 3u));
+					uint32_t w = n0 | (n1 << 8) | (n2 << 16) | (n3 << 24);
+					uint32_t wl = (uint32_t)__shfl((int)w, (int)(lane - 4u));
+					H = lane >= 4u && lane < 16u ? wl : H;
+				}
+			}
+			if (cs_eof(c, wb))
+				return -EIO;
+			*reinterpret_cast<uint32_t *>(stage + 4u * lane) = H;
+			sd_emit_staged(o, stage, mbidx, lane);
+		}
+
+		/* what the next macroblocks look at: the row context of this
+		 * column (bottom rows of the grids) and word 0 */
+		{
+			const bool gb = (LN.g_role & CS_ROLE_BOT) != 0;
+			const bool lb = (LN.l_role & CS_ROLE_BOT) != 0;
+			if (gb) {
+				rowent[LN.g_off] = (uint8_t)G[0];
+				if (c444) {
+					rowent[LN.g_off + 4u] = (uint8_t)G[1];
+					rowent[LN.g_off + 8u] = (uint8_t)G[2];
+				}
+			}
+			if (!S.is_i && lb) {
+				rowent[LN.l_off] = (uint8_t)LL[0];
+				rowent[LN.l_off + 12u] = (uint8_t)LL[1];
+			}
+			if (lane == 0)
+				*reinterpret_cast<uint32_t *>(rowent) = me;
+		}
+		left = me;
+		mbx++;
+		if (mbx == S.W)
+			mbx = 0;
+		mbidx++;
+		mb_count = mbidx;
+		const uint32_t end = cs_term(c, wb); /* end_of_slice_flag */
+		if (cs_eof(c, wb))
+			return -EIO;
+		if (end)
+			break;
+	}
+	return 0;
+}
+
+extern "C" __global__ void __launch_bounds__(64 * CS_WAVES_PER_BLOCK, 4)
+h264_amd_k_decode_cabac(cs_args a)
+{
+	extern __shared__ __attribute__((aligned(16))) uint8_t lds_all[];
+	/* the (m, n) tables of all 1024 contexts: shared by the workgroup */
+	{
+		const uint4 *s = reinterpret_cast<const uint4 *>(&a.tab->mn[0][0][0]);
+		uint4 *d = reinterpret_cast<uint4 *>(lds_all);
+		for (uint32_t i = threadIdx.x; i < CS_MN_BYTES / 16u;
+		     i += 64u * CS_WAVES_PER_BLOCK)
+			d[i] = s[i];
+	}
+	__syncthreads();
+	/* from here on the waves of the workgroup are independent */
+	const int8_t *mn = reinterpret_cast<const int8_t *>(lds_all);
+	const uint32_t wave = wb_uniform(threadIdx.x >> 6);
+	uint8_t *lds = lds_all + CS_MN_BYTES + wave * a.wave_lds_bytes;
+	uint8_t *ring = lds + CS_RING_OFF;
+	uint8_t *stage = lds + CS_STAGE_OFF;
+	uint8_t *row = lds + CS_ROW_OFF;
+	const uint32_t lane = wb_lane();
+	const uint32_t slice = blockIdx.x * CS_WAVES_PER_BLOCK + wave;
+	if (slice >= a.n)
+		return;
+
+	struct h264_amd_slice_result r;
+	sd_load_uniform(&r, a.results + slice);
+	/* only what the first kernel left as "CABAC, header parsed, data raw" */
+	if (r.status != 0 || !(r.flags & H264_AMD_SR_HEADER_OK) ||
+	    !(r.flags & H264_AMD_SR_CABAC) || (r.flags & H264_AMD_SR_DATA_PARSED))
+		return;
+	struct h264_amd_slice_desc d;
+	sd_load_uniform(&d, a.descs + slice);
+	const struct h264_slice_header *hdr = a.headers + slice;
+
+	int status = 0;
+	uint32_t mb_count = 0;
+	OutCtx o;
+	o.tier = a.tier;
+	o.mb_stride = a.mb_stride;
+	o.rec_bytes = sd_t2_stride(r.chroma_array_type);
+	o.mb_out = a.mb_out ? a.mb_out + (size_t)slice * a.mb_capacity * a.mb_stride
+			    : nullptr;
+	if (o.mb_out == nullptr)
+		o.tier = H264_AMD_TIER_NONE;
+	o.t0acc = 0;
+	o.lo = o.hi = 0;
+
+	SwParams P;
+	{
+		uint32_t e = d.epoch < a.n_epochs ? d.epoch : 0u;
+		status = sw_activate(P, cb_hdr(hdr, WOFF(pic_parameter_set_id)), a.spsv,
+				     a.ppsv, a.epochs + e, a.n_sps, a.n_pps);
+	}
+	CbSlice S;
+	S.type = (uint32_t)r.slice_type;
+	S.cat = r.chroma_array_type;
+	S.W = r.pic_width_in_mbs;
+	S.field = cb_hdr(hdr, WOFF(field_pic_flag)) ? 1u : 0u;
+	S.is_b = S.type == H264_SLICE_TYPE_B;
+	S.is_si = S.type == H264_SLICE_TYPE_SI;
+	S.is_i = S.type == H264_SLICE_TYPE_I || S.is_si;
+	S.nref0 = cb_hdr(hdr, WOFF(num_ref_idx_l0_active_minus1));
+	S.nref1 = cb_hdr(hdr, WOFF(num_ref_idx_l1_active_minus1));
+	S.t8mode = S.direct8x8 = 0;
+	S.bdl = S.bdc = 8;
+	S.pcm_chroma = 0;
+	if (status == 0) {
+		if ((P.sps.mb_adaptive_frame_field_flag && !P.sps.frame_mbs_only_flag &&
+		     !S.field) ||
+		    P.pps.num_slice_groups_minus1 > 0 || S.W == 0 || S.W > a.row_pitch)
+			status = H264_AMD_E_UNSUPPORTED;
+		S.t8mode = P.pps.transform_8x8_mode_flag;
+		S.direct8x8 = P.sps.direct_8x8_inference_flag;
+		S.bdl = P.sps.bit_depth_luma;
+		S.bdc = P.sps.bit_depth_chroma;
+		S.pcm_chroma = S.cat == 1 ? 64u : S.cat == 2 ? 128u : S.cat == 3 ? 256u : 0u;
+	}
+
+	WaveBits wb;
+	wb_open(wb, a.buf + d.offset, d.size, ring,
+		reinterpret_cast<uint32_t *>(lds + CS_STATE_OFF), lane);
+	CbEng c;
+	c.V = c.k = c.bins = 0;
+	c.range = 510;
+	if (status == 0) {
+		/* to the end of the slice header, where the first kernel stopped */
+		uint32_t left = r.end_bit;
+		while (left) {
+			uint32_t k = left < 512u ? left : 512u;
+			wb_skip(wb, k);
+			wb_sync(wb, lane);
+			left -= k;
+		}
+		/* 9.3.1.1: the context variables, from the (m, n) tables in LDS
+		 * straight into the lanes of their registers */
+		CbCtx x;
+		{
+			const uint32_t idc = cb_hdr(hdr, WOFF(cabac_init_idc));
+			const bool valid = S.is_i || idc <= 2;
+			const uint32_t col = S.is_i ? 0u : 1u + (valid ? idc : 0u);
+			uint32_t regs[CX_REGS];
+#pragma unroll
+			for (uint32_t q = 0; q < CX_REGS; q++) {
+				const uint32_t ci = a.dtab->slot_ctx[S.field][q][lane];
+				const uint32_t cj = ci < 1024u ? ci : 0u;
+				uint32_t s = cabac_state_init(r.slice_qp,
+							      mn[8u * cj + 2u * col],
+							      mn[8u * cj + 2u * col + 1u]);
+				/* pStateIdx | valMPS << 6 */
+				s = (s & 63u) | ((s >> 8) << 6);
+				regs[q] = valid && ci < 1024u ? s : 0u;
+			}
+			x.mb0 = regs[CX_MB0];
+			x.mb1 = regs[CX_MB1];
+#pragma unroll
+			for (uint32_t q = 0; q < 3; q++) {
+				x.sig[q] = regs[CX_SIG + q];
+				x.last[q] = regs[CX_LAST + q];
+				x.abs[q] = regs[CX_ABS + q];
+				x.m8[q] = regs[CX_M8 + q];
+			}
+		}
+		{
+			const uint8_t *q = &a.tab->range_lps[lane][0];
+			c.lps4 = (uint32_t)q[0] | ((uint32_t)q[1] << 8) |
+				 ((uint32_t)q[2] << 16) | ((uint32_t)q[3] << 24);
+			c.trans = (uint32_t)a.tab->next_lps[lane] |
+				  (lane == 0 ? 64u : 0u) |
+				  ((uint32_t)a.tab->next_mps[lane] << 8);
+			c.pos8 = a.dtab->pos8[S.field][lane];
+		}
+		status = cs_slice_data(c, wb, x, stage, row, o, lane, S,
+				       r.first_mb_in_slice, a.mb_capacity, mb_count,
+				       a.prio_div ? (blockIdx.x / a.prio_div) & 3u : 0u,
+				       a.prio_div ? 1u : 0u);
+	}
+
+	/* T0: flush the partial last group of 64 words */
+	if (o.tier == H264_AMD_TIER_T0 && (mb_count & 63u) != 0) {
+		uint32_t base = mb_count & ~63u;
+		uint32_t l = lane < (mb_count & 63u) ? lane : (mb_count & 63u) - 1u;
+		uint32_t v = (uint32_t)__shfl((int)o.t0acc, (int)l);
+		*reinterpret_cast<uint32_t *>(o.mb_out + (size_t)(base + l) * o.mb_stride) = v;
+	}
+	uint32_t lo = o.lo, hi = o.hi;
+#pragma unroll
+	for (int sft = 32; sft >= 1; sft >>= 1) {
+		lo += (uint32_t)__shfl_xor((int)lo, sft);
+		hi += (uint32_t)__shfl_xor((int)hi, sft);
+	}
+	r.status = status;
+	if (status != H264_AMD_E_UNSUPPORTED)
+		r.flags |= H264_AMD_SR_DATA_PARSED;
+	r.mb_count = mb_count;
+	r.end_bit = status == 0 ? cs_pos(c, wb) : 0u;
+	r.checksum = ((uint64_t)hi << 32) | lo;
+	if (a.bins != nullptr && lane == 0)
+		a.bins[slice] = c.bins;
+	{
+		const uint32_t *src = reinterpret_cast<const uint32_t *>(&r);
+		uint32_t *dst = reinterpret_cast<uint32_t *>(a.results + slice);
+		uint32_t k = lane & 15u, v = src[0];
+#pragma unroll
+		for (uint32_t j = 1; j < 16; j++)
+			v = k == j ? src[j] : v;
+		dst[k] = v;
+	}
+}
+
+#endif /* H264_AMD_CABAC_SLICE_HIP */

@@ -856,7 +856,10 @@ static int c_residual_luma(struct cd *c, uint32_t comp)
 {
 	struct orc_mb *mb = c->mb;
 	const int i16 = mb->MbPartPredMode[0] == ORC_PRED_Intra_16x16;
+	/* Table 9-42: DC / AC / 4x4 blocks of a component are ctxBlockCat cat0 +
+	 * 0 / 1 / 2, its 8x8 block is 5, 9 or 13 */
 	const uint32_t cat0 = comp == 0 ? 0 : comp == 1 ? 6 : 10;
+	const uint32_t cat8 = comp == 0 ? 5 : comp == 1 ? 9 : 13;
 	uint32_t i8, i4, k, coded = 0;
 	uint32_t addrA, idxA, addrB, idxB;
 
@@ -886,7 +889,7 @@ static int c_residual_luma(struct cd *c, uint32_t comp)
 					      2 * (yW / 8) + xW / 8);
 				inc = (int32_t)(ca + 2 * cb);
 			}
-			CHK(c_block(c, cat0 + 5, mb->Lvl8x8[comp][i8], 64, inc, &coded));
+			CHK(c_block(c, cat8, mb->Lvl8x8[comp][i8], 64, inc, &coded));
 			if (coded)
 				c->info->cbf[comp] |= (uint16_t)(0xfu << (4 * i8));
 			/* the record keeps the 4x4 view CAVLC reads

@@ -1,5 +1,6 @@
-"""GPU parity for the CABAC subset kernel (h264_amd_k_decode_cabac_subset,
-engine extension H264_AMD_READER_FLAGS_CABAC_SUBSET) through the C-ABI,
+"""GPU parity for the CABAC kernel (h264_amd_k_decode_cabac, engine extension
+H264_AMD_READER_FLAGS_CABAC) on the part of the syntax that has reference
+behaviour -- what the reference's writers emit -- through the C-ABI,
 against the oracle's CPU statement of the same decoder: results, header
 images, macroblock records in every tier -- on the reference writers' own
 slices (round trip), on slices from the independent Python encoder, and on
@@ -146,7 +147,7 @@ def test_damaged_and_foreign_cabac_data(engine):
         nals.append(mutate(nal, rnd) if (k % 8) >= 3 else nal)
     ref, res = compare(engine, head, nals, cap=200)
     st = [r.status for r in res]
-    assert st.count(0) > 40 and st.count(-38) > 10 and st.count(-5) > 5
+    assert st.count(0) > 40 and st.count(-5) > 5
 
 
 def test_mixed_batch_with_cavlc_and_capacity(engine):
