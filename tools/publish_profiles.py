@@ -44,7 +44,7 @@ def main():
            s["read_ceiling"]["GBps"], s["scan_1gib"]["achieved_GBps"],
            s["scan_1gib"]["frac_measured"], s["write_back"]["achieved_GBps"],
            s["write_back"]["frac_measured"], s["c4_64mib"]["ms_per_step"],
-           s["cabac_subset_decode"]["ms"], s["cabac_encode"]["ms"]))
+           s["cabac_skip_decode"]["ms"], s["cabac_encode"]["ms"]))
     pm = json.loads(last_json(os.path.join(g, "pmc_decode.log")))
     print("per MB: SALU %.0f VALU %.0f branch %.0f LDS %.1f" %
           (pm["SQ_INSTS_SALU_per_mb"], pm["SQ_INSTS_VALU_per_mb"],
