@@ -360,12 +360,6 @@ H264_API int h264_amd_decode_slices(struct h264_amd_engine *eng,
 				    const struct h264_amd_params *params,
 				    const struct h264_amd_decode_args *args);
 
-/* Bins (context-coded, bypass and terminating) the CABAC pass of the LAST
- * h264_amd_decode_slices() call decoded for each of its first n slices (0 for
- * a slice it did not walk): the unit the CABAC rate is quoted in.  Synchronous. */
-H264_API int h264_amd_cabac_bins(struct h264_amd_engine *eng, uint32_t *dst,
-				 uint32_t n);
-
 /* ---- slice write-back (round trip) -------------------------------------- */
 struct h264_amd_write_args {
 	const uint8_t *d_src; /* original NAL bytes (raw slice data source) */

@@ -51,7 +51,6 @@ def engine_lib():
     L.h264_amd_copy.argtypes = [vp, vp, vp, sz]
     L.h264_amd_last_kernel_ms.argtypes = [vp, C.c_char_p,
                                           C.POINTER(C.c_float)]
-    L.h264_amd_cabac_bins.argtypes = [vp, vp, C.c_uint32]
     L.h264_amd_params_new.argtypes = [C.POINTER(vp)]
     L.h264_amd_params_destroy.argtypes = [vp]
     L.h264_amd_params_reset.argtypes = [vp]
@@ -241,14 +240,6 @@ class Engine:
         return out.reshape(n, head_bytes)
 
     # -- slice decode -----------------------------------------------------
-    def cabac_bins(self, n):
-        """bins each of the first n slices of the last decode launch took in
-        the CABAC pass (numpy uint32)"""
-        out = np.zeros(n, dtype=np.uint32)
-        _check(engine_lib().h264_amd_cabac_bins(
-            self.h, out.ctypes.data_as(C.c_void_p), n), "cabac_bins")
-        return out
-
     def decode_slices(self, params, d_buf, descs, reader_flags=1,
                       tier=TIER_NONE, mb_capacity=0, want_headers=False,
                       cat=1, d_descs=None, outputs=None, sync=True):

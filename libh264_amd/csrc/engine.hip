@@ -18,6 +18,7 @@
 #include <string.h>
 
 #include <new>
+#include <type_traits>
 #include <vector>
 
 #define H264_API_EXPORTS 1
@@ -92,9 +93,6 @@ struct h264_amd_engine {
 	dev_vlc_tables *d_vlc;
 	cabac_tables *d_cabac;
 	cabac_dec_tables *d_cabac_dec;
-	uint32_t *d_cabac_bins; /* bins per slice of the last CABAC pass */
-	size_t cap_cabac_bins;
-	uint32_t cabac_bins_n;
 	/* device copy of the last params object used */
 	const h264_amd_params *params_src;
 	uint64_t params_serial;
@@ -307,7 +305,6 @@ extern "C" int h264_amd_engine_destroy(struct h264_amd_engine *e)
 	hipFree(e->d_vlc);
 	hipFree(e->d_cabac);
 	hipFree(e->d_cabac_dec);
-	hipFree(e->d_cabac_bins);
 	hipFree(e->d_sps);
 	hipFree(e->d_pps);
 	hipFree(e->d_fmo);
@@ -824,18 +821,6 @@ extern "C" int h264_amd_decode_slices(struct h264_amd_engine *e,
 					     ? e->cu_count
 					     : 0u;
 		}
-		if (c.n > e->cap_cabac_bins) {
-			hipFree(e->d_cabac_bins);
-			e->d_cabac_bins = NULL;
-			e->cap_cabac_bins = 0;
-			HIP_TRY(hipMalloc((void **)&e->d_cabac_bins,
-					  (size_t)c.n * sizeof(uint32_t)));
-			e->cap_cabac_bins = c.n;
-		}
-		HIP_TRY(hipMemsetAsync(e->d_cabac_bins, 0, (size_t)c.n * sizeof(uint32_t),
-				       e->stream));
-		c.bins = e->d_cabac_bins;
-		e->cabac_bins_n = c.n;
 		size_t clds = CS_MN_BYTES + (size_t)CS_WAVES_PER_BLOCK * c.wave_lds_bytes;
 		if (clds > 160u * 1024u)
 			return -E2BIG;

@@ -1584,6 +1584,17 @@ static void put_slice_header(struct gen *g)
 	}
 }
 
+/* bins (context coded, bypass, terminating) of all CABAC slices generated so far */
+static uint64_t s_stat_bins;
+
+uint64_t h264gen_stat_cabac_bins(int reset)
+{
+	uint64_t v = __atomic_load_n(&s_stat_bins, __ATOMIC_RELAXED);
+	if (reset)
+		__atomic_store_n(&s_stat_bins, 0, __ATOMIC_RELAXED);
+	return v;
+}
+
 size_t h264gen_slice_bound(const struct h264gen_cfg *cfg,
 			   const struct h264gen_slice *sl)
 {
@@ -1820,6 +1831,7 @@ int h264gen_slice_nal(const struct h264gen_cfg *cfg,
 		}
 	}
 	if (g.cabac) {
+		__atomic_add_fetch(&s_stat_bins, g.ce.bins, __ATOMIC_RELAXED);
 		/* the encoder's flush wrote the stop bit (9.3.4.5) */
 		while (g.w.nbits != 0)
 			bw_u(&g.w, 0, 1);

@@ -126,6 +126,11 @@ long h264gen_mb_to_slice_group_map(const struct h264gen_cfg *cfg,
 				   uint32_t slice_group_change_cycle,
 				   uint32_t field_pic, uint8_t *map, size_t cap);
 
+/* Bins (context coded, bypass and terminating) the generator's arithmetic
+ * encoder has coded in all CABAC slices so far -- the unit a CABAC decoder's rate
+ * is quoted in; reset != 0 starts the count again. */
+uint64_t h264gen_stat_cabac_bins(int reset);
+
 /* Worst-case size of one slice NAL for a config (for sizing `cap`). */
 size_t h264gen_slice_bound(const struct h264gen_cfg *cfg,
 			   const struct h264gen_slice *sl);

@@ -159,8 +159,6 @@ struct cs_args {
 	/* workgroups per dispatch layer (see slice_decode.hip, "fair shares");
 	 * 0: no priority rotation */
 	uint32_t prio_div;
-	/* optional [n]: bins decoded per slice (bench statistics) */
-	uint32_t *bins;
 };
 
 __device__ __forceinline__ uint32_t cb_hdr(const struct h264_slice_header *h,
@@ -174,10 +172,10 @@ __device__ __forceinline__ uint32_t cb_hdr(const struct h264_slice_header *h,
 struct CbEng {
 	/* codIOffset << k | the next k bits of the stream; codIRange; k <= 23 */
 	uint32_t V, range, k;
-	uint32_t bins;
-	/* per lane: rangeTabLPS[lane][0..3]; transIdxLPS | flip << 6 | transIdxMPS
-	 * << 8 (flip: valMPS changes on an LPS in state 0); Table 9-43 */
-	uint32_t lps4, trans, pos8;
+	/* per lane (= pStateIdx): rangeTabLPS[lane][0..3]; transIdxLPS | flip << 6
+	 * (flip: valMPS changes on an LPS in state 0); transIdxMPS; Table 9-43 by
+	 * levelListIdx */
+	uint32_t lps4, trl, trm, pos8;
 };
 
 __device__ __forceinline__ uint32_t cs_rl(uint32_t v, uint32_t l)
@@ -239,26 +237,29 @@ __device__ __forceinline__ bool cs_eof(const CbEng &c, const WaveBits &wb)
 	return wb_all_in(wb) && cs_pos(c, wb) > wb_total_bits(wb);
 }
 
-/* 9.3.3.2.1 DecodeDecision on the context in lane `slot` of `reg` */
+/* 9.3.3.2.1 DecodeDecision on the context in lane `slot` of `reg`.  A state is
+ * pStateIdx | valMPS << 6 and serves as a lane select as it is: the hardware
+ * looks at six bits (tools/probe/lane_probe.hip).  The rangeTabLPS column of
+ * the current codIRange is extracted in all 64 lanes (one v_bfe), so that the
+ * state picks its value with one v_readlane and nothing is left to shift on the
+ * scalar side. */
 __device__ __forceinline__ uint32_t cs_dec(CbEng &c, WaveBits &wb, uint32_t &reg,
 					   uint32_t slot)
 {
 	cs_refill(c, wb);
+	const uint32_t col = (c.lps4 >> ((c.range >> 3) & 24u)) & 0xffu; /* per lane */
 	const uint32_t s = cs_rl(reg, slot);
-	const uint32_t idx = s & 63u;
-	const uint32_t l4 = cs_rl(c.lps4, idx), tr = cs_rl(c.trans, idx);
-	const uint32_t rl = (l4 >> ((c.range >> 3) & 24u)) & 0xffu;
+	const uint32_t rl = cs_rl(col, s);
+	const uint32_t tl = cs_rl(c.trl, s), tm = cs_rl(c.trm, s);
 	const uint32_t rm = c.range - rl;
 	const uint32_t T = rm << c.k;
 	const bool lps = c.V >= T;
 	c.V -= lps ? T : 0u;
 	c.range = lps ? rl : rm;
-	const uint32_t ns = (lps ? (tr & 0xffu) : (tr >> 8)) ^ (s & 64u);
-	reg = cs_wl(reg, ns, slot);
+	reg = cs_wl(reg, (lps ? tl : tm) ^ (s & 64u), slot);
 	const uint32_t n = (uint32_t)__builtin_clz(c.range) - 23u;
 	c.range <<= n;
 	c.k -= n;
-	c.bins++;
 	return (s >> 6) ^ (lps ? 1u : 0u);
 }
 
@@ -270,7 +271,6 @@ __device__ __forceinline__ uint32_t cs_bypass(CbEng &c, WaveBits &wb)
 	const uint32_t T = c.range << c.k;
 	const bool b = c.V >= T;
 	c.V -= b ? T : 0u;
-	c.bins++;
 	return b ? 1u : 0u;
 }
 
@@ -279,7 +279,6 @@ __device__ __forceinline__ uint32_t cs_term(CbEng &c, WaveBits &wb)
 {
 	cs_refill(c, wb);
 	c.range -= 2u;
-	c.bins++;
 	if (c.V >= (c.range << c.k))
 		return 1;
 	const uint32_t n = (uint32_t)__builtin_clz(c.range) - 23u;
@@ -449,7 +448,9 @@ __device__ __forceinline__ uint32_t
 cs_block(CbEng &c, WaveBits &wb, uint32_t &sreg, uint32_t &lreg, uint32_t &areg,
 	 uint32_t s_off, uint32_t a_off, uint32_t numc, uint32_t nc8, bool &ok)
 {
-	uint64_t sig = 0;
+	/* positions with a coefficient: 64 bits only where a block has them */
+	typedef typename std::conditional<IS8, uint64_t, uint32_t>::type mask_t;
+	mask_t sig = 0;
 	uint32_t i = 0;
 	bool last = false;
 	for (; i + 1u < numc; i++) {
@@ -465,7 +466,7 @@ cs_block(CbEng &c, WaveBits &wb, uint32_t &sreg, uint32_t &lreg, uint32_t &areg,
 			si = li = s_off + i;
 		}
 		if (cs_dec(c, wb, sreg, si)) {
-			sig |= 1ull << i;
+			sig |= (mask_t)1 << i;
 			if (cs_dec(c, wb, lreg, li)) {
 				last = true;
 				break;
@@ -473,11 +474,12 @@ cs_block(CbEng &c, WaveBits &wb, uint32_t &sreg, uint32_t &lreg, uint32_t &areg,
 		}
 	}
 	if (!last)
-		sig |= 1ull << (numc - 1u);
+		sig |= (mask_t)1 << (numc - 1u);
 	uint32_t coef = 0, eq1 = 0, gt1 = 0;
 	while (sig) {
-		const uint32_t p = 63u - (uint32_t)__builtin_clzll(sig);
-		sig &= ~(1ull << p);
+		const uint32_t p = IS8 ? 63u - (uint32_t)__builtin_clzll(sig)
+				       : 31u - (uint32_t)__builtin_clz((uint32_t)sig);
+		sig &= ~((mask_t)1 << p);
 		uint32_t a = 0;
 		if (cs_dec(c, wb, areg,
 			   a_off + (gt1 ? 0u : (eq1 < 3u ? 1u + eq1 : 4u)))) {
@@ -730,8 +732,11 @@ cs_slice_data(CbEng &c, WaveBits &wb, CbCtx &x, uint8_t *stage, uint8_t *row,
 				LL[0] = LL[1] = 0;
 			} else {
 				/* ---- derived macroblock variables ---- */
-				uint32_t nparts = 1, use[4] = {0, 0, 0, 0};
-				uint32_t shape[4] = {0, 0, 0, 0}; /* sub-mb partition shape */
+				/* per partition, two bits each: which lists it uses
+				 * (L0 = 1, L1 = 2, Bi = 3, none / direct = 0) and the
+				 * shape of its sub-macroblock partitions (0 8x8, 1 8x4,
+				 * 2 4x8, 3 4x4) */
+				uint32_t nparts = 1, usem = 0, shapem = 0;
 				uint32_t pshape = 0; /* 0 16x16, 1 16x8, 2 8x16, 3 8x8 */
 				bool direct16 = false;
 				if (is_intra) {
@@ -753,14 +758,14 @@ cs_slice_data(CbEng &c, WaveBits &wb, CbCtx &x, uint8_t *stage, uint8_t *row,
 					mb_type = H264_MB_TYPE_P_16x16 + raw;
 					pshape = raw;
 					nparts = raw == 0 ? 1u : raw == 3 ? 4u : 2u;
-					use[0] = use[1] = use[2] = use[3] = 1;
+					usem = 0x55;
 				} else if (raw == 0) {
 					mb_type = H264_MB_TYPE_B_Direct_16x16;
 					direct16 = true;
 					me |= CS_NB_BDIR;
 				} else if (raw <= 3u) {
 					mb_type = H264_MB_TYPE_B_16x16;
-					use[0] = raw;
+					usem = raw;
 				} else if (raw <= 21u) {
 					const uint32_t e = (raw - 4u) >> 1;
 					mb_type = (raw & 1u) ? H264_MB_TYPE_B_8x16
@@ -768,8 +773,8 @@ cs_slice_data(CbEng &c, WaveBits &wb, CbCtx &x, uint8_t *stage, uint8_t *row,
 					pshape = (raw & 1u) ? 2u : 1u;
 					nparts = 2;
 					/* Table 7-14: L0 = 1, L1 = 2, Bi = 3 */
-					use[0] = (0x3f999u >> (2u * e)) & 3u;
-					use[1] = (0x39f69u >> (2u * e)) & 3u;
+					usem = ((0x3f999u >> (2u * e)) & 3u) |
+					       (((0x39f69u >> (2u * e)) & 3u) << 2);
 				} else {
 					mb_type = H264_MB_TYPE_B_8x8;
 					pshape = 3;
@@ -801,8 +806,7 @@ cs_slice_data(CbEng &c, WaveBits &wb, CbCtx &x, uint8_t *stage, uint8_t *row,
 								st = 1;
 							else
 								st = cs_dec(c, wb, x.mb0, 23) ? 2u : 3u;
-							use[p] = 1;
-							shape[p] = st;
+							shapem |= st << (2u * p);
 						} else {
 							if (!cs_dec(c, wb, x.mb0, 36)) {
 								st = 0;
@@ -826,19 +830,21 @@ cs_slice_data(CbEng &c, WaveBits &wb, CbCtx &x, uint8_t *stage, uint8_t *row,
 								}
 							}
 							/* Table 7-18 */
-							use[p] = st == 0   ? 0u
-								 : st <= 3 ? st
-								 : st <= 9 ? 1u + ((st - 4u) >> 1)
-									   : st - 9u;
-							shape[p] = st <= 3   ? 0u
-								   : st <= 9 ? 1u + (st & 1u)
-									     : 3u;
+							const uint32_t u = st == 0   ? 0u
+									   : st <= 3 ? st
+									   : st <= 9 ? 1u + ((st - 4u) >> 1)
+										     : st - 9u;
+							const uint32_t sh = st <= 3   ? 0u
+									    : st <= 9 ? 1u + (st & 1u)
+										      : 3u;
+							usem = (usem & ~(3u << (2u * p))) | (u << (2u * p));
+							shapem |= sh << (2u * p);
 						}
 						pred_lo |= st << (8u * p);
 						if (S.is_b && st == 0) {
 							if (!S.direct8x8)
 								no_sub8 = false;
-						} else if (shape[p] != 0) {
+						} else if ((shapem >> (2u * p)) & 3u) {
 							no_sub8 = false;
 						}
 					}
@@ -885,7 +891,7 @@ cs_slice_data(CbEng &c, WaveBits &wb, CbCtx &x, uint8_t *stage, uint8_t *row,
 							continue;
 						uint32_t refw = 0;
 						for (uint32_t p = 0; p < nparts; p++) {
-							if (!(use[p] & (1u << l)))
+							if (!((usem >> (2u * p)) & (1u << l)))
 								continue;
 							uint32_t x8, y8, w8, h8;
 							if (pshape == 3) {
@@ -928,13 +934,13 @@ cs_slice_data(CbEng &c, WaveBits &wb, CbCtx &x, uint8_t *stage, uint8_t *row,
 #pragma unroll
 					for (uint32_t l = 0; l < 2; l++) {
 						for (uint32_t p = 0; p < nparts; p++) {
-							if (!(use[p] & (1u << l)))
+							if (!((usem >> (2u * p)) & (1u << l)))
 								continue;
-							const uint32_t nsub =
-								pshape != 3	? 1u
-								: shape[p] == 0 ? 1u
-								: shape[p] == 3 ? 4u
-										: 2u;
+							const uint32_t shp = (shapem >> (2u * p)) & 3u;
+							const uint32_t nsub = pshape != 3 ? 1u
+									      : shp == 0  ? 1u
+									      : shp == 3  ? 4u
+											  : 2u;
 							for (uint32_t s = 0; s < nsub; s++) {
 								uint32_t x4, y4, w4, h4;
 								if (pshape != 3) {
@@ -943,7 +949,7 @@ cs_slice_data(CbEng &c, WaveBits &wb, CbCtx &x, uint8_t *stage, uint8_t *row,
 									w4 = pshape == 2 ? 2u : 4u;
 									h4 = pshape == 1 ? 2u : 4u;
 								} else {
-									const uint32_t sh = shape[p];
+									const uint32_t sh = shp;
 									x4 = 2u * (p & 1u);
 									y4 = 2u * (p >> 1);
 									w4 = h4 = 2;
@@ -1291,7 +1297,11 @@ cs_slice_data(CbEng &c, WaveBits &wb, CbCtx &x, uint8_t *stage, uint8_t *row,
 
 		/* what the next macroblocks look at: the row context of this
 		 * column (bottom rows of the grids) and word 0 */
-		{
+		if (skip) {
+			/* nothing coded: the entry is word 0 and zeros */
+			if (lane < CS_ROW_STRIDE / 4u)
+				reinterpret_cast<uint32_t *>(rowent)[lane] = lane ? 0u : me;
+		} else {
 			const bool gb = (LN.g_role & CS_ROLE_BOT) != 0;
 			const bool lb = (LN.l_role & CS_ROLE_BOT) != 0;
 			if (gb) {
@@ -1406,7 +1416,7 @@ h264_amd_k_decode_cabac(cs_args a)
 	wb_open(wb, a.buf + d.offset, d.size, ring,
 		reinterpret_cast<uint32_t *>(lds + CS_STATE_OFF), lane);
 	CbEng c;
-	c.V = c.k = c.bins = 0;
+	c.V = c.k = 0;
 	c.range = 510;
 	if (status == 0) {
 		/* to the end of the slice header, where the first kernel stopped */
@@ -1450,9 +1460,8 @@ h264_amd_k_decode_cabac(cs_args a)
 			const uint8_t *q = &a.tab->range_lps[lane][0];
 			c.lps4 = (uint32_t)q[0] | ((uint32_t)q[1] << 8) |
 				 ((uint32_t)q[2] << 16) | ((uint32_t)q[3] << 24);
-			c.trans = (uint32_t)a.tab->next_lps[lane] |
-				  (lane == 0 ? 64u : 0u) |
-				  ((uint32_t)a.tab->next_mps[lane] << 8);
+			c.trl = (uint32_t)a.tab->next_lps[lane] | (lane == 0 ? 64u : 0u);
+			c.trm = (uint32_t)a.tab->next_mps[lane];
 			c.pos8 = a.dtab->pos8[S.field][lane];
 		}
 		status = cs_slice_data(c, wb, x, stage, row, o, lane, S,
@@ -1480,8 +1489,6 @@ h264_amd_k_decode_cabac(cs_args a)
 	r.mb_count = mb_count;
 	r.end_bit = status == 0 ? cs_pos(c, wb) : 0u;
 	r.checksum = ((uint64_t)hi << 32) | lo;
-	if (a.bins != nullptr && lane == 0)
-		a.bins[slice] = c.bins;
 	{
 		const uint32_t *src = reinterpret_cast<const uint32_t *>(&r);
 		uint32_t *dst = reinterpret_cast<uint32_t *>(a.results + slice);

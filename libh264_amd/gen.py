@@ -34,11 +34,18 @@ def lib():
         L.h264gen_mb_to_slice_group_map.restype = C.c_long
         L.h264gen_mb_to_slice_group_map.argtypes = [
             C.POINTER(GenCfg), C.c_uint32, C.c_uint32, C.c_void_p, C.c_size_t]
+        L.h264gen_stat_cabac_bins.restype = C.c_uint64
+        L.h264gen_stat_cabac_bins.argtypes = [C.c_int]
         L.h264gen_slice_bound.restype = C.c_size_t
         L.h264gen_slice_bound.argtypes = [C.POINTER(GenCfg),
                                           C.POINTER(GenSlice)]
         _LIB = L
     return _LIB
+
+
+def cabac_bins(reset=False):
+    """bins coded by the generator's CABAC encoder since the last reset"""
+    return int(lib().h264gen_stat_cabac_bins(1 if reset else 0))
 
 
 def cfg_1080p(**kw):

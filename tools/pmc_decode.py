@@ -33,6 +33,9 @@ def main():
     ap.add_argument("--slices", type=int, default=1024)
     ap.add_argument("--lib", default="")
     ap.add_argument("--out", default="/tmp/pmc_decode")
+    ap.add_argument("--cabac", action="store_true",
+                    help="the CABAC kernel on tools/bench_cabac.py's slices; "
+                         "values per BIN instead of per macroblock")
     ap.add_argument("--mix", default="",
                     help="a macroblock mix of tools/bench_mix.py instead of the "
                          "bench batch")
@@ -49,6 +52,9 @@ def main():
         if args.mix:
             prog = [os.path.join(ROOT, "tools", "bench_mix.py"), "--only",
                     args.mix, "--slices", str(args.slices), "--reps", "1"]
+        if args.cabac:
+            prog = [os.path.join(ROOT, "tools", "bench_cabac.py"), "--slices",
+                    str(args.slices), "--reps", "1"]
         cmd = ["rocprofv3", "--kernel-trace", "--pmc"] + grp + \
             ["--output-format", "csv", "-d", d, "--", sys.executable] + prog
         p = subprocess.run(cmd, cwd="/tmp", env=env, stdout=subprocess.PIPE,
@@ -60,7 +66,8 @@ def main():
         for f in glob.glob(os.path.join(d, "**", "*counter_collection.csv"),
                            recursive=True):
             for row in csv.DictReader(open(f)):
-                if not row["Kernel_Name"].startswith(KERNEL):
+                if not row["Kernel_Name"].startswith(
+                        "h264_amd_k_decode_cabac" if args.cabac else KERNEL):
                     continue
                 c = row["Counter_Name"]
                 res[c] = res.get(c, 0.0) + float(row["Counter_Value"])
@@ -71,8 +78,16 @@ def main():
     mbs = 8160.0 * args.slices
     out = {"slices": args.slices, "lib": os.path.basename(args.lib) or
            "in-tree", "mix": args.mix or "bench batch"}
+    unit = "_per_mb"
+    if args.cabac:
+        # the bins of the batch: from the generator, as bench_cabac.py counts them
+        sys.path.insert(0, os.path.join(ROOT, "tools"))
+        import bench_cabac
+        mbs = float(bench_cabac.workload(args.slices, 16)[4])
+        unit = "_per_bin"
+        out["mix"] = "C3 CABAC P-slices"
     for c, v in res.items():
-        out[c + "_per_mb"] = round(v / mbs, 2)
+        out[c + unit] = round(v / mbs, 3 if args.cabac else 2)
     print(json.dumps(out))
 
 
