@@ -25,6 +25,10 @@ with it.
       point-to-point scatter of the slice bytes -> decode on every rank ->
       all-gather of the result records (libh264_amd/pipeline.py); strong
       scaling.
+  c1: BASELINE config 1 -- tools/h264_dump/h264-dump (this repository's dump
+      tool over the drop-in libh264.so) on one 1080p Annex-B file, beside the
+      CPU port of the same reader; one slice = one wavefront, printed whichever
+      side wins.
   c5: BASELINE config 5 -- the writer round trip: every rank parses the
       headers of its own S slices and re-emits them with
       h264_amd_k_write_slices, byte-identical to the input; weak scaling, no
@@ -421,6 +425,93 @@ def c3_real(eng, n, cores, reps):
         "gen_seconds": round(gen_s, 1)}
 
 
+def run_c1(args, cores):
+    """BASELINE config 1: tools/h264_dump on ONE 1080p Annex-B file (SPS, PPS,
+    one Baseline-profile CAVLC IDR I-slice) through the drop-in library, beside
+    the CPU port of the same reader -- printed whichever side wins.  The tool
+    runs as a child process (this one never touches the GPU)."""
+    import orc
+    from libh264_amd import gen, build
+    from libh264_amd.ctypes_abi import GenSlice
+    import tempfile
+    cfg = gen.cfg_1080p()
+    s = GenSlice(slice_type=7, idr=1, nal_ref_idc=3, first_mb=0, num_mbs=8160,
+                 pm_i16x16=280, pm_pcm=2, density=5, pm_escape=5,
+                 pm_cbp_zero=50, pm_zero_pcm=100, seed=17)
+    sps_nal, pps_nal, nal = gen.sps(cfg), gen.pps(cfg), gen.slice_nal(cfg, s)
+    data = b"".join(b"\x00\x00\x00\x01" + n for n in (sps_nal, pps_nal, nal))
+    tool = build.build_tools()
+    tmp = tempfile.NamedTemporaryFile(suffix=".h264", delete=False)
+    tmp.write(data)
+    tmp.close()
+    passes = max(3, args.steps)
+
+    def tool_run(extra):
+        p = subprocess.run([tool] + extra + ["--bench", str(passes), tmp.name],
+                           stdout=subprocess.PIPE, stderr=subprocess.PIPE,
+                           text=True, timeout=600)
+        lines = [l for l in p.stderr.splitlines() if l.startswith("{")]
+        if p.returncode != 0 or not lines:
+            raise SystemExit("h264-dump failed: rc %d\n%s" %
+                             (p.returncode, p.stderr[-2000:]))
+        return json.loads(lines[-1])
+
+    dump = tool_run([])
+    rsd = tool_run(["--reader-slice-data"])
+    os.unlink(tmp.name)
+    if dump["ok"] != 3 or dump["mismatches"] or rsd["ok"] != 3 or \
+            rsd["slice_data_mb_callbacks"] != 8160:
+        raise SystemExit("h264-dump: %r %r" % (dump, rsd))
+    # the CPU port of h264_reader_parse(SLICE_DATA) on the same slice, one
+    # thread, repeated to about two seconds
+    buf = np.frombuffer(nal, dtype=np.uint8)
+    reps = 160
+    o = np.zeros(reps, dtype=np.uint64)
+    z = np.full(reps, len(nal), dtype=np.uint32)
+    secs, mbs, byts = C.c_double(), C.c_uint64(), C.c_uint64()
+    rc = orc.lib().orc_bench_slices(
+        buf.ctypes.data_as(C.c_void_p), o.ctypes.data_as(C.c_void_p),
+        z.ctypes.data_as(C.c_void_p), reps, sps_nal, len(sps_nal), pps_nal,
+        len(pps_nal), 1, 1, C.byref(secs), C.byref(mbs), C.byref(byts))
+    if rc != 0 or mbs.value != 8160 * reps:
+        raise SystemExit("cpu port failed: rc %d" % rc)
+    cpu_ms = 1e3 * secs.value / reps
+    ms = rsd["ms_per_pass"]
+    emit({
+        "metric": "bitstream_parsed_mbit_per_s",
+        "value": round(8e-3 * len(data) / ms, 1), "unit": "Mbit/s",
+        "n_gpus": 1, "steps": passes, "warmup": 1, "ms_per_step": round(ms, 3),
+        "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+        "dtype": "u8", "data": "synthetic",
+        "macroblocks_per_s": round(8160e3 / ms, 1),
+        "config": {
+            "workload": "C1: tools/h264_dump/h264-dump --reader-slice-data on "
+                        "one %d-byte 1080p Annex-B file (SPS, PPS, one Baseline "
+                        "CAVLC IDR I-slice of 8160 macroblocks) through "
+                        "libh264.so: h264_reader_parse with "
+                        "H264_READER_FLAGS_SLICE_DATA, a slice_data_mb "
+                        "callback per macroblock, per-NAL dump + write-back "
+                        "compare; host buffer in, PCIe and launch included" %
+                        len(data),
+            "parallelism": "one slice = one wavefront: the call pattern a GPU "
+                           "loses on"},
+        "roofline": None,
+        "cpu_baseline": {
+            "value": round(8e-3 * len(nal) / cpu_ms, 1), "unit": "Mbit/s",
+            "cores": 1, "kind": "port",
+            "ms_per_picture": round(cpu_ms, 3),
+            "mb_per_s": round(8160e3 / cpu_ms, 1),
+            "sample": "the same slice %d times through the oracle's reader "
+                      "with slice_data, one thread, %.1f s" % (reps, secs.value)},
+        "gpu_vs_cpu_port": round(cpu_ms / ms, 3),
+        "tool_default_mode": {
+            "what": "the reference tool's default: reader flags 0, "
+                    "h264_dump_nalu(H264_DUMP_FLAGS_SLICE_DATA): slice data "
+                    "decoded at the full-syntax tier and printed as JSON",
+            "ms_per_pass": dump["ms_per_pass"], "best_ms": dump["best_ms"]},
+        "tool_reader_slice_data": rsd})
+
+
 def run_c4(args, dist, rank, world, local_rank, cores):
     """BASELINE config 4, strong scaling: rank 0 holds the stream."""
     import libh264_amd  # noqa: F401
@@ -605,10 +696,13 @@ def run_c5(args, dist, rank, world, share, eng, params, d_buf, descs, d_descs,
 
 def main():
     ap = argparse.ArgumentParser()
-    ap.add_argument("--workload", default="c2", choices=["c2", "c4", "c5"],
+    ap.add_argument("--workload", default="c2",
+                    choices=["c1", "c2", "c4", "c5"],
                     help="c2: batch of I-slices (BASELINE config 2, the "
                          "headline); c4: one mixed Annex-B stream through scan "
-                         "+ scatter + decode + gather (config 4)")
+                         "+ scatter + decode + gather (config 4); c5: writer "
+                         "round trip; c1: the h264-dump tool on one 1080p file "
+                         "beside the CPU port (config 1)")
     ap.add_argument("--mib", type=int, default=64,
                     help="c4: stream size in MiB")
     ap.add_argument("--gpus", type=int, default=1)
@@ -627,6 +721,11 @@ def main():
     if args.gpus < 1:
         raise SystemExit("--gpus must be at least 1")
 
+    if args.workload == "c1":
+        if args.gpus != 1:
+            raise SystemExit("c1 is one file through one reader: --gpus 1")
+        run_c1(args, 16)
+        return
     if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
         sys.exit(spawn_ranks(args))
     keep_stdout_for_the_result()

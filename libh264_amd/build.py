@@ -137,10 +137,25 @@ def build_host(force=False):
     return out
 
 
+def build_tools(force=False):
+    """tools/h264_dump/h264-dump: the dump tool of BASELINE config 1 over the
+    drop-in library (a plain C program against include/h264/h264.h)."""
+    src = os.path.join(ROOT, "tools", "h264_dump", "h264_dump.c")
+    out = os.path.join(ROOT, "tools", "h264_dump", "h264-dump")
+    host = build_host()
+    if host is None or not os.path.exists(src):
+        return None
+    if force or _newer(out, [src, host]):
+        _run(["gcc", "-std=gnu99", "-O2", "-Wall", "-I" + INC, src, "-o", out,
+              "-L" + LIB, "-lh264", "-lh264_amd_engine",
+              "-Wl,-rpath,$ORIGIN/../../libh264_amd/lib"])
+    return out
+
+
 def build_all(force=False):
     os.makedirs(LIB, exist_ok=True)
     return {"gen": build_gen(force), "engine": build_engine(force),
-            "host": build_host(force)}
+            "host": build_host(force), "tools": build_tools(force)}
 
 
 if __name__ == "__main__":

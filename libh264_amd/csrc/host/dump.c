@@ -21,8 +21,10 @@
  * slice NAL unit is put together again by the writer, decoded by the
  * slice-decode kernel at the full-syntax tier, and the macroblock records are
  * printed with the reference's keys -- "mb_addr" = frame_num * 10000 + mbAddr
- * (:619), coefficient keys "Luma(blk,idx)" (:228-236).  CABAC slice data and
- * MBAFF / slice groups: none, like the parse.
+ * (:619), coefficient keys "Luma(blk,idx)" (:228-236).  MBAFF frames and
+ * slice groups are decoded on the device like everything else (macroblock
+ * addresses from the map the launch built); CABAC slice data is not dumped,
+ * like the reference's parse (src/h264_syntax_slice_data.h:715-717).
  *
  * The reference's own output is not available in this image (json-c absent):
  * the TEXT of the dump is unpinned; tests walk it the way the reference's
