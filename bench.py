@@ -357,7 +357,7 @@ def c3_real(eng, n, cores, reps):
     params = Params()
     params.put_sps(head.sps[0])
     epoch = params.put_pps(head.pps[0])
-    order = np.argsort(-sizes.astype(np.int64), kind="stable")
+    order = np.arange(n)  # the engine orders the launch itself
     descs = np.zeros(n, dtype=[("offset", "<u8"), ("size", "<u4"),
                                ("epoch", "<u4")])
     descs["offset"], descs["size"], descs["epoch"] = offs[order], sizes[order], epoch
@@ -793,8 +793,9 @@ def main():
     params.put_sps(sps)
     epoch = params.put_pps(pps)
 
-    # largest slices first: the last wavefronts to start are the shortest
-    order = shard.longest_first(sizes)
+    # descriptors in generation order: the engine puts the longest slices at
+    # the head of the launch itself (h264_amd_k_order_slices)
+    order = np.arange(args.slices)
     descs = np.zeros(args.slices, dtype=[("offset", "<u8"), ("size", "<u4"),
                                          ("epoch", "<u4")])
     descs["offset"] = offs[order]

@@ -101,6 +101,9 @@ struct h264_amd_engine {
 	dev_fmo *d_fmo;
 	dev_epoch *d_epochs;
 	size_t cap_sps, cap_pps, cap_fmo, cap_epochs;
+	uint32_t *d_order; /* launch position -> slice, longest first */
+	size_t cap_order;
+	int use_order; /* H264_AMD_ORDER=0: positions in descriptor order (A/B runs) */
 	uint8_t *d_fmo_map; /* per-slice macroblock-to-slice-group maps */
 	size_t cap_fmo_map;
 	uint32_t fmo_stride, fmo_n; /* of the last decode launch */
@@ -259,6 +262,10 @@ extern "C" int h264_amd_engine_new(int device, void *hip_stream,
 		for (int k = 0; k < 2; k++)
 			NEW_TRY(hipEventCreate(&e->ev[f][k]));
 	{
+		const char *v = getenv("H264_AMD_ORDER");
+		e->use_order = !(v != NULL && v[0] == '0');
+	}
+	{
 		const char *v = getenv("H264_AMD_SCAN_SEG");
 		unsigned long seg = v ? strtoul(v, NULL, 0) : 0;
 		if (seg >= SCAN_BLOCK_BYTES && seg <= (1u << 30) &&
@@ -309,6 +316,7 @@ extern "C" int h264_amd_engine_destroy(struct h264_amd_engine *e)
 	hipFree(e->d_pps);
 	hipFree(e->d_fmo);
 	hipFree(e->d_fmo_map);
+	hipFree(e->d_order);
 	hipFree(e->d_epochs);
 	scan_scratch_free(&e->scan);
 	hipFree(e->d_avcc_nals);
@@ -763,6 +771,26 @@ extern "C" int h264_amd_decode_slices(struct h264_amd_engine *e,
 	void (*kern)(sd_args) = params->any_mbaff ? h264_amd_k_decode_slices_mbaff :
 				w5 ? h264_amd_k_decode_slices_w5 :
 				     h264_amd_k_decode_slices;
+	const uint32_t per_simd = (kern == h264_amd_k_decode_slices_w5) ? 5u : 4u;
+	const uint32_t wgs = (a.n + SD_WAVES_PER_BLOCK - 1) / SD_WAVES_PER_BLOCK;
+	/* Slice data walked and more slices than a handful: launch positions
+	 * stand for the slices longest first (h264_amd_k_order_slices on the
+	 * device) -- the workgroup dispatcher then hands the long slices out
+	 * first and fills the end of the launch with the short ones, whatever
+	 * order the caller's descriptors are in. */
+	const bool ordered = e->use_order && a.n > 64u &&
+			     (args->reader_flags & H264_READER_FLAGS_SLICE_DATA);
+	if (ordered) {
+		if ((size_t)a.n > e->cap_order) {
+			hipFree(e->d_order);
+			e->d_order = NULL;
+			e->cap_order = 0;
+			HIP_TRY(hipMalloc((void **)&e->d_order,
+					  (size_t)a.n * sizeof(uint32_t)));
+			e->cap_order = (size_t)a.n;
+		}
+		a.order = e->d_order;
+	}
 	{
 		/* Priority rotation (slice_decode.hip, "fair shares"): pays when
 		 * the waves of the last round all end together -- a launch of
@@ -771,9 +799,7 @@ extern "C" int h264_amd_decode_slices(struct h264_amd_engine *e,
 		 * filled last round the oldest-first order is the better one: the
 		 * early finishers hand their slots to it sooner (5632 slices:
 		 * 96.2 against 100.6 ms). */
-		const uint32_t per_simd = (kern == h264_amd_k_decode_slices_w5) ? 5u : 4u;
 		const uint32_t cap = e->cu_count * 4u * per_simd; /* resident waves */
-		const uint32_t wgs = (a.n + SD_WAVES_PER_BLOCK - 1) / SD_WAVES_PER_BLOCK;
 		const bool fits = a.n <= cap, whole = a.n % cap == 0;
 		a.prio_div = wgs > e->cu_count && (fits || whole) ? e->cu_count : 0u;
 	}
@@ -782,9 +808,13 @@ extern "C" int h264_amd_decode_slices(struct h264_amd_engine *e,
 			(const void *)kern,
 			hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
 	HIP_TRY(hipEventRecord(e->ev[FAM_DECODE][0], e->stream));
-	hipLaunchKernelGGL(kern,
-			   dim3((a.n + SD_WAVES_PER_BLOCK - 1) / SD_WAVES_PER_BLOCK),
-			   dim3(64 * SD_WAVES_PER_BLOCK), lds, e->stream, a);
+	if (ordered) {
+		hipLaunchKernelGGL(h264_amd_k_order_slices, dim3(1), dim3(1024), 0,
+				   e->stream, a.descs, a.n, e->d_order);
+		HIP_TRY(hipGetLastError());
+	}
+	hipLaunchKernelGGL(kern, dim3(wgs), dim3(64 * SD_WAVES_PER_BLOCK), lds,
+			   e->stream, a);
 	HIP_TRY(hipGetLastError());
 	HIP_TRY(hipEventRecord(e->ev[FAM_DECODE][1], e->stream));
 	e->timed[FAM_DECODE] = true;
@@ -812,6 +842,7 @@ extern "C" int h264_amd_decode_slices(struct h264_amd_engine *e,
 		c.headers = a.headers;
 		c.mb_out = a.mb_out;
 		c.row_pitch = a.row_pitch;
+		c.order = a.order;
 		c.wave_lds_bytes =
 			(CS_ROW_OFF + CS_ROW_STRIDE * c.row_pitch + 255u) & ~255u;
 		{

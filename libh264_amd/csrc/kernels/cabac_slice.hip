@@ -159,6 +159,7 @@ struct cs_args {
 	/* workgroups per dispatch layer (see slice_decode.hip, "fair shares");
 	 * 0: no priority rotation */
 	uint32_t prio_div;
+	const uint32_t *order; /* launch position -> slice, or NULL */
 };
 
 __device__ __forceinline__ uint32_t cb_hdr(const struct h264_slice_header *h,
@@ -1354,7 +1355,12 @@ h264_amd_k_decode_cabac(cs_args a)
 	uint8_t *stage = lds + CS_STAGE_OFF;
 	uint8_t *row = lds + CS_ROW_OFF;
 	const uint32_t lane = wb_lane();
-	const uint32_t slice = blockIdx.x * CS_WAVES_PER_BLOCK + wave;
+	/* launch positions stand for the slices longest first (slice_decode.hip,
+	 * h264_amd_k_order_slices) */
+	const uint32_t q = blockIdx.x * CS_WAVES_PER_BLOCK + wave;
+	if (q >= a.n)
+		return;
+	const uint32_t slice = a.order ? wb_uniform(a.order[q]) : q;
 	if (slice >= a.n)
 		return;
 

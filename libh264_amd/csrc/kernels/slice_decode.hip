@@ -2206,24 +2206,20 @@ struct sd_args {
 	 * age rank of a wave on its SIMD is blockIdx.x / prio_div; 0: the launch
 	 * fits one layer, no priority rotation */
 	uint32_t prio_div;
+	/* launch position -> slice, longest first (h264_amd_k_order_slices);
+	 * NULL: position = slice */
+	const uint32_t *order;
 };
 
+/* one slice NAL unit, start to finish, by this wavefront */
 template <bool WITH_MBAFF>
-__device__ __forceinline__ void sd_kernel_body(const sd_args &a)
+__device__ __forceinline__ void sd_one_slice(const sd_args &a, const uint32_t slice,
+					     uint8_t *lds_all, uint8_t *lds,
+					     const uint32_t lane)
 {
-	extern __shared__ __attribute__((aligned(16))) uint8_t lds_all[];
-	vlc_stage_tables(lds_all, a.vlc, threadIdx.x, 64u * SD_WAVES_PER_BLOCK);
-	__syncthreads();
-	/* from here on the waves of the workgroup are independent */
-	const uint32_t wave = wb_uniform(threadIdx.x >> 6);
-	uint8_t *lds = lds_all + SD_TABS_BYTES + wave * a.wave_lds_bytes;
 	uint8_t *ring = lds + SD_RING_OFF;
 	uint8_t *stage = lds + SD_STAGE_OFF;
 	uint8_t *row = lds + SD_ROW_OFF;
-	const uint32_t lane = wb_lane();
-	const uint32_t slice = blockIdx.x * SD_WAVES_PER_BLOCK + wave;
-	if (slice >= a.n)
-		return;
 
 	struct h264_amd_slice_desc d;
 	sd_load_uniform(&d, a.descs + slice);
@@ -2455,6 +2451,78 @@ __device__ __forceinline__ void sd_kernel_body(const sd_args &a)
 		for (uint32_t j = 1; j < 16; j++)
 			v = k == j ? src[j] : v;
 		dst[k] = v;
+	}
+}
+
+/* Work distribution inside a launch (hard part 5): the
+ * hardware's workgroup dispatcher is the queue.  Workgroups start in index order
+ * as wave slots come free; position q of the launch stands for slice order[q],
+ * LONGEST FIRST (h264_amd_k_order_slices on the device: no caller has to sort),
+ * so the four slices of a workgroup are of a size and end together, and what
+ * starts last is what is shortest.  Results go out under the slice's own index.
+ * A loop per wave over an atomic counter -- the persistent-wave form of the
+ * same idea -- was built and measured: bit-exact, but the loop around the
+ * slice body costs the register allocator 104 spilled vector registers (0
+ * without it) and the bench batch 54.5 -> 61.8 ms, 5632 slices 101 -> 148 ms
+ * (profiles/r03_decode_queue_ab.jsonl); laundering the table pointers against
+ * hoisting, -disable-machine-licm and an out-of-line slice function did not
+ * bring them back. */
+template <bool WITH_MBAFF>
+__device__ __forceinline__ void sd_kernel_body(const sd_args &a)
+{
+	extern __shared__ __attribute__((aligned(16))) uint8_t lds_all[];
+	vlc_stage_tables(lds_all, a.vlc, threadIdx.x, 64u * SD_WAVES_PER_BLOCK);
+	__syncthreads();
+	/* from here on the waves of the workgroup are independent */
+	const uint32_t wave = wb_uniform(threadIdx.x >> 6);
+	uint8_t *lds = lds_all + SD_TABS_BYTES + wave * a.wave_lds_bytes;
+	const uint32_t lane = wb_lane();
+	const uint32_t q = blockIdx.x * SD_WAVES_PER_BLOCK + wave;
+	if (q >= a.n)
+		return;
+	const uint32_t slice = a.order ? wb_uniform(a.order[q]) : q;
+	if (slice < a.n)
+		sd_one_slice<WITH_MBAFF>(a, slice, lds_all, lds, lane);
+}
+
+/* Longest-first order of a batch: slices bucketed by size (5 bits of exponent, 5
+ * of mantissa: 3 % resolution), buckets laid out from the largest down; inside
+ * a bucket slices keep no particular order.  One workgroup. */
+__device__ __forceinline__ uint32_t sd_size_bucket(uint32_t size)
+{
+	if (size < 32u)
+		return size;
+	const uint32_t e = 31u - (uint32_t)__builtin_clz(size);
+	return (e - 4u) * 32u + ((size >> (e - 5u)) & 31u);
+}
+
+extern "C" __global__ void __launch_bounds__(1024)
+h264_amd_k_order_slices(const struct h264_amd_slice_desc *descs, uint32_t n,
+			uint32_t *order)
+{
+	__shared__ uint32_t hist[1024], scan[1024];
+	const uint32_t t = threadIdx.x;
+	hist[t] = 0;
+	__syncthreads();
+	for (uint32_t i = t; i < n; i += 1024u)
+		atomicAdd(&hist[sd_size_bucket(descs[i].size)], 1u);
+	__syncthreads();
+	/* scan[t] = slices in buckets above 1023 - t ... i.e. a prefix sum over
+	 * the buckets in descending order */
+	scan[t] = hist[1023u - t];
+	__syncthreads();
+	for (uint32_t d = 1; d < 1024u; d <<= 1) {
+		uint32_t v = t >= d ? scan[t - d] : 0u;
+		__syncthreads();
+		scan[t] += v;
+		__syncthreads();
+	}
+	/* first position of bucket b: the sum over the buckets above it */
+	hist[1023u - t] = scan[t] - hist[1023u - t];
+	__syncthreads();
+	for (uint32_t i = t; i < n; i += 1024u) {
+		uint32_t pos = atomicAdd(&hist[sd_size_bucket(descs[i].size)], 1u);
+		order[pos] = i;
 	}
 }
 

@@ -38,7 +38,8 @@ def child(args):
         params = Params()
         params.put_sps(rec.sps[0])
         epoch = params.put_pps(rec.pps[0])
-        order = shard.longest_first(sizes)
+        order = (shard.longest_first(sizes) if args.host_sorted else
+                 np.arange(n))
         descs = np.zeros(n, dtype=[("offset", "<u8"), ("size", "<u4"),
                                    ("epoch", "<u4")])
         descs["offset"], descs["size"], descs["epoch"] = \
@@ -66,7 +67,8 @@ def child(args):
             "mmb_per_s": round(mbs / float(np.median(ms)) / 1e3, 1),
             "gbit_per_s": round(8e-6 * float(sizes.sum()) /
                                 float(np.median(ms)), 2),
-            "bad_slices": bad,
+            "bad_slices": bad, "host_sorted": args.host_sorted,
+            "engine_order": os.environ.get("H264_AMD_ORDER", "1") != "0",
             "results_sha1": hashlib.sha1(raw.tobytes()).hexdigest()[:16],
         }), flush=True)
         del d_buf, d_descs, out
@@ -78,6 +80,10 @@ def main():
     ap.add_argument("--slices", default="4096")
     ap.add_argument("--steps", type=int, default=10)
     ap.add_argument("--child", action="store_true")
+    ap.add_argument("--host-sorted", action="store_true",
+                    help="descriptors longest first already on the host (the "
+                         "engine orders its launches itself, H264_AMD_ORDER=0 "
+                         "turns that off)")
     ap.add_argument("libs", nargs="*")
     args = ap.parse_args()
     if args.child:
@@ -87,7 +93,8 @@ def main():
         if lib:
             env["H264_AMD_ENGINE_LIB"] = os.path.abspath(lib)
         subprocess.run([sys.executable, os.path.abspath(__file__), "--child",
-                        "--slices", args.slices, "--steps", str(args.steps)],
+                        "--slices", args.slices, "--steps", str(args.steps)] +
+                       (["--host-sorted"] if args.host_sorted else []),
                        env=env, check=False)
 
 
