@@ -590,9 +590,14 @@ def run_c4(args, dist, rank, world, local_rank, cores):
                             "bytes -> decode on every rank -> all-gather of "
                             "the result records" % (len(data) / 2 ** 20,
                                                     plan.n_nals, n),
-                "parallelism": "slices of one stream size-balanced over %d "
-                               "GPU(s); RCCL send/recv scatter + all-gather" %
-                               world},
+                "parallelism": "slices of one stream size-balanced over the "
+                               "ranks that get work: %d of %d GPU(s) "
+                               "(h264_amd_group_plan: min(world, ceil(slices / "
+                               "1024))); RCCL send/recv scatter of pieces "
+                               "packed by h264_amd_pack + all-gather of "
+                               "device-resident records" %
+                               (plan.ranks_used, world)},
+            "ranks_used": plan.ranks_used,
             "stage_ms_per_step": {k: round(1e3 * v / args.steps, 3)
                                   for k, v in timing.items()},
             "roofline": {

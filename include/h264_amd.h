@@ -270,6 +270,8 @@ H264_API const struct h264_sps *
 h264_amd_params_sps(const struct h264_amd_params *p, uint32_t sps_id);
 H264_API const struct h264_pps *
 h264_amd_params_pps(const struct h264_amd_params *p, uint32_t pps_id);
+/* 1 if any PPS version seen so far has num_slice_groups_minus1 > 0 */
+H264_API int h264_amd_params_has_slice_groups(const struct h264_amd_params *p);
 /* largest PicSizeInMbs over every SPS version seen: a safe mb_capacity */
 H264_API uint32_t h264_amd_params_max_mbs(const struct h264_amd_params *p);
 
@@ -454,6 +456,100 @@ H264_API int h264_amd_slice_group_maps(struct h264_amd_engine *e, uint32_t first
 				       uint32_t count, uint8_t *dst,
 				       size_t dst_pitch, size_t size);
 H264_API size_t h264_amd_slice_group_map_pitch(const struct h264_amd_engine *e);
+
+/* ---- engine group: one batch, several devices --------------------------------- */
+/* Slices are independent entropy-coded units: a batch shards
+ * by slice.  A group is N engines of ONE process, one per device; a decode call
+ * takes the same arguments as h264_amd_decode_slices() with every buffer on the
+ * FIRST member's device and
+ *   1. plans on the host: the members that get work -- min(N, ceil(n / 1024)), a
+ *      batch that fills less than a quarter of one chip is not scattered -- and a
+ *      size-balanced assignment, longest slice first to the least loaded member;
+ *   2. packs each other member's slices into one contiguous piece on the first
+ *      device (gather kernel) and sends it with ONE device-to-device copy per
+ *      member -- point to point: on xGMI every peer has its own link;
+ *   3. decodes on every member at once (the first member reads the caller's
+ *      buffer in place);
+ *   4. brings the result records (and header images / macroblock records when
+ *      asked for) back and scatters them into the caller's arrays in the
+ *      caller's order.
+ * The reference has no counterpart (it is single threaded, one NAL unit per
+ * call, src/h264_reader.c:117-162).  libh264.so uses a group when
+ * H264_AMD_DEVICES=0,1,... names more than one device.  Slice groups (FMO) maps
+ * stay with the member that built them: h264_amd_slice_group_map() is not
+ * available through a group; a caller that needs them decodes on one engine. */
+struct h264_amd_group;
+
+/* The device layer a group runs on.  h264_amd_group_new() uses the library's
+ * own (HIP: an engine per device, hipMemcpyPeerAsync between them); a test
+ * substitutes host memory and its own decoder through
+ * h264_amd_group_new_with_ops().  `member` is the index in the group; every call
+ * returns 0 or -errno; copies and launches may be asynchronous on the member's
+ * stream, sync() waits for all of that member's work. */
+struct h264_amd_group_ops {
+	void *ctx;
+	int (*alloc)(void *ctx, uint32_t member, size_t size, void **d_ptr);
+	int (*free)(void *ctx, uint32_t member, void *d_ptr);
+	int (*upload)(void *ctx, uint32_t member, void *d_dst, const void *src,
+		      size_t size);
+	int (*download)(void *ctx, uint32_t member, void *dst, const void *d_src,
+			size_t size);
+	/* d_dst on dst_member <- d_src on src_member */
+	int (*copy)(void *ctx, uint32_t dst_member, void *d_dst, uint32_t src_member,
+		    const void *d_src, size_t size);
+	/* on `member`: for i < n  d_dst[d_dst_off[i] ..] = d_src[d_src_off[i] .. +
+	 * d_sizes[i]) */
+	int (*pack)(void *ctx, uint32_t member, uint8_t *d_dst, const uint8_t *d_src,
+		    const uint64_t *d_src_off, const uint64_t *d_dst_off,
+		    const uint32_t *d_sizes, uint32_t n);
+	/* on `member`: for j < n  row d_index[j] of d_dst = row j of d_src; rows
+	 * of row_bytes bytes, a multiple of 16 */
+	int (*scatter_rows)(void *ctx, uint32_t member, uint8_t *d_dst,
+			    const uint8_t *d_src, const uint32_t *d_index, uint32_t n,
+			    size_t row_bytes);
+	int (*decode)(void *ctx, uint32_t member, const struct h264_amd_params *params,
+		      const struct h264_amd_decode_args *args);
+	int (*sync)(void *ctx, uint32_t member);
+};
+
+/* devices: n HIP ordinals (the first one holds the caller's buffers) */
+H264_API int h264_amd_group_new(const int *devices, uint32_t n,
+				struct h264_amd_group **ret);
+H264_API int h264_amd_group_new_with_ops(const struct h264_amd_group_ops *ops,
+					 uint32_t n, struct h264_amd_group **ret);
+H264_API int h264_amd_group_destroy(struct h264_amd_group *g);
+H264_API uint32_t h264_amd_group_size(const struct h264_amd_group *g);
+/* member i's engine (NULL for a group on foreign ops) */
+H264_API struct h264_amd_engine *h264_amd_group_engine(struct h264_amd_group *g,
+						       uint32_t i);
+
+/* The plan alone (host arithmetic, no device): members used and, per slice, the
+ * member that gets it.  sizes[n] in bytes; owner[n] out. */
+H264_API uint32_t h264_amd_group_plan(const uint32_t *sizes, uint32_t n,
+				      uint32_t members, uint32_t *owner);
+/* the same with the threshold spelled out: members used = min(members,
+ * ceil(n / min_per_member)); h264_amd_group_plan() uses 1024 */
+H264_API uint32_t h264_amd_group_plan_ex(const uint32_t *sizes, uint32_t n,
+					 uint32_t members, uint32_t min_per_member,
+					 uint32_t *owner);
+/* The group's gather kernel on one engine, for a caller that transports the
+ * pieces itself (one process per GPU over RCCL: libh264_amd/pipeline.py): for
+ * i < n  d_dst[d_dst_off[i] ..] = d_src[d_src_off[i] .. + d_sizes[i]); all
+ * arrays on the device, d_dst_off 16-byte aligned.  Asynchronous. */
+H264_API int h264_amd_pack(struct h264_amd_engine *eng, uint8_t *d_dst,
+			   const uint8_t *d_src, const uint64_t *d_src_off,
+			   const uint64_t *d_dst_off, const uint32_t *d_sizes,
+			   uint32_t n);
+
+/* Like h264_amd_decode_slices() on the first member's device, spread over the
+ * group.  h_descs: the host's copy of args->d_descs if the caller has one (else
+ * NULL: fetched).  *members_used (optional) reports how many members got work.
+ * Synchronous. */
+H264_API int h264_amd_group_decode_slices(struct h264_amd_group *g,
+					  const struct h264_amd_params *params,
+					  const struct h264_amd_decode_args *args,
+					  const struct h264_amd_slice_desc *h_descs,
+					  uint32_t *members_used);
 
 /* ---- calibration and identification ---------------------------------------- */
 

@@ -17,6 +17,7 @@
 #include <stdio.h>
 #include <string.h>
 
+#include <algorithm>
 #include <new>
 #include <type_traits>
 #include <vector>
@@ -459,6 +460,11 @@ extern "C" int h264_amd_params_reset(struct h264_amd_params *p)
 	return 0;
 }
 
+extern "C" int h264_amd_params_has_slice_groups(const struct h264_amd_params *p)
+{
+	return p != NULL && p->n_fmo > 0;
+}
+
 extern "C" int h264_amd_params_epoch(const struct h264_amd_params *p)
 {
 	return p ? (int)p->epochs.size() - 1 : -EINVAL;
@@ -871,3 +877,4 @@ extern "C" int h264_amd_decode_slices(struct h264_amd_engine *e,
 }
 
 #include "engine_more.inc"
+#include "group.inc"

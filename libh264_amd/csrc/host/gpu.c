@@ -12,12 +12,38 @@
 
 static pthread_once_t g_once = PTHREAD_ONCE_INIT;
 static struct h264_amd_engine *g_engine;
+static struct h264_amd_group *g_group; /* H264_AMD_DEVICES=0,1,...: several */
 static int g_engine_err = -ENODEV;
 
 static void engine_init(void)
 {
 	const char *dev = getenv("H264_AMD_DEVICE");
+	const char *devs = getenv("H264_AMD_DEVICES");
 	int ordinal = 0;
+	if (devs != NULL && strchr(devs, ',') != NULL && h264_amd_available()) {
+		/* a list of HIP ordinals: an engine group; the first one holds
+		 * the reader's and writer's buffers */
+		int list[64];
+		uint32_t n = 0;
+		const char *p = devs;
+		while (*p != '\0' && n < 64) {
+			char *end = NULL;
+			long v = strtol(p, &end, 10);
+			if (end == p)
+				break;
+			list[n++] = (int)v;
+			p = *end == ',' ? end + 1 : end;
+		}
+		if (n > 1) {
+			g_engine_err = h264_amd_group_new(list, n, &g_group);
+			if (g_engine_err == 0) {
+				g_engine = h264_amd_group_engine(g_group, 0);
+				return;
+			}
+			g_group = NULL;
+			return;
+		}
+	}
 	if (dev == NULL || *dev == '\0')
 		dev = getenv("LOCAL_RANK");
 	if (dev != NULL && *dev != '\0')
@@ -36,6 +62,13 @@ int h264_host_engine(struct h264_amd_engine **ret)
 	pthread_once(&g_once, engine_init);
 	*ret = g_engine;
 	return g_engine != NULL ? 0 : (g_engine_err < 0 ? g_engine_err : -ENODEV);
+}
+
+/* the engine group of H264_AMD_DEVICES, or NULL: one device */
+struct h264_amd_group *h264_host_group(void)
+{
+	pthread_once(&g_once, engine_init);
+	return g_group;
 }
 
 /* the engine's stream, events and timing slots are shared by every reader and

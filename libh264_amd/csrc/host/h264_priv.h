@@ -137,6 +137,7 @@ int h264_host_slice_header(const struct h264_ctx *ctx, const uint8_t *nal,
 /* process-wide engine on device $H264_AMD_DEVICE (default 0); -ENODEV when
  * there is no usable GPU */
 int h264_host_engine(struct h264_amd_engine **ret);
+struct h264_amd_group *h264_host_group(void);
 int h264_host_grow(void **d_ptr, size_t *cap, size_t want);
 void h264_host_lock(void);
 void h264_host_unlock(void);

@@ -346,7 +346,18 @@ static int batch_fetch(struct h264_reader *rd, struct rd_batch *b, size_t idx)
 	a.d_headers = rd->d_headers;
 	a.d_mb_out = mb_bytes ? rd->d_mb : NULL;
 	a.mb_stride = mb_bytes ? 4 : 0;
-	res = h264_amd_decode_slices(b->eng, rd->params, &a);
+	{
+		/* H264_AMD_DEVICES names several devices: the chunk is spread over
+		 * the engine group (a small one stays on the first device, see
+		 * h264_amd_group_plan).  Slice group maps live with the engine
+		 * that built them: streams with slice groups stay on one device. */
+		struct h264_amd_group *grp = h264_host_group();
+		if (grp != NULL && !h264_amd_params_has_slice_groups(rd->params))
+			res = h264_amd_group_decode_slices(grp, rd->params, &a, NULL,
+							   NULL);
+		else
+			res = h264_amd_decode_slices(b->eng, rd->params, &a);
+	}
 	if (res == 0)
 		res = h264_amd_download(b->eng, rd->h_results, rd->d_results,
 					cn * sizeof(*rd->h_results));

@@ -29,7 +29,31 @@ import numpy as np
 from . import shard
 
 DESC_DTYPE = np.dtype([("offset", "<u8"), ("size", "<u4"), ("epoch", "<u4")])
-ALIGN = 1  # the decode kernel takes NAL units at any byte offset
+ALIGN = 16  # pieces of the gather kernel (h264_amd_pack) start 16-byte aligned
+MIN_SLICES_PER_RANK = 1024  # a quarter of one chip's wave slots
+
+
+def partition(sizes, world, min_per_rank=MIN_SLICES_PER_RANK):
+    """The engine's own plan (h264_amd_group_plan_ex, the code the in-process
+    engine group runs): ranks that get work -- min(world, ceil(n /
+    min_per_rank)), a stream that fills less than a quarter of one chip is not
+    scattered -- and the size-balanced assignment, longest slice first to the
+    least loaded rank.  Returns (list of index arrays, one per rank of the
+    WORLD, ascending; ranks_used)."""
+    from . import capi
+    sizes = np.ascontiguousarray(sizes, dtype=np.uint32)
+    n = len(sizes)
+    if n == 0:
+        return [np.zeros(0, dtype=np.int64) for _ in range(world)], 0
+    L = capi.engine_lib()
+    L.h264_amd_group_plan_ex.restype = C.c_uint32
+    L.h264_amd_group_plan_ex.argtypes = [C.c_void_p, C.c_uint32, C.c_uint32,
+                                         C.c_uint32, C.c_void_p]
+    owner = np.zeros(n, dtype=np.uint32)
+    used = L.h264_amd_group_plan_ex(sizes.ctypes.data, n, world, min_per_rank,
+                                    owner.ctypes.data)
+    return [np.flatnonzero(owner == r).astype(np.int64)
+            for r in range(world)], int(used)
 
 
 class Plan:
@@ -40,6 +64,7 @@ class Plan:
         self.descs = descs  # DESC_DTYPE array, stream order
         self.n_nals = n_nals
         self.consumed = consumed
+        self.ranks_used = 1  # set by run_step: ranks that got slices
 
 
 def _host_lib():
@@ -161,7 +186,8 @@ def scatter_slices(dist, ops, stream, plan, parts, src=0):
     return local, ldescs
 
 
-def run_step(dist, ops, stream, length, cap, src=0, timing=None):
+def run_step(dist, ops, stream, length, cap, src=0, timing=None,
+             min_per_rank=MIN_SLICES_PER_RANK):
     """One pass of the whole pipeline.  Returns (result table in stream order
     as uint8 [n, 64], plan).  `timing`: dict receiving wall seconds per stage
     (device work synchronised at the stage boundaries when given)."""
@@ -184,7 +210,7 @@ def run_step(dist, ops, stream, length, cap, src=0, timing=None):
     epochs_after = [replay.put(kind, raw) for kind, raw in plan.ps_nals]
     if hasattr(ops, "note_plan"):
         ops.note_plan(plan, epochs_after)
-    parts = shard.balance(plan.descs["size"], world)
+    parts, plan.ranks_used = partition(plan.descs["size"], world, min_per_rank)
     t = mark("broadcast", t)
     local, ldescs = scatter_slices(dist, ops, stream, plan, parts, src)
     t = mark("scatter", t)
@@ -225,11 +251,14 @@ class EngineOpsPlain:
         n = len(ldescs)
         if n == 0:
             return np.zeros((0, 64), dtype=np.uint8)
-        reuse = self._out if self._out and self._out["n"] == n else None
+        key = (n, ldescs.tobytes())
+        if getattr(self, "_desc_key", None) != key:
+            self._desc_key = key
+            self._d_descs = self.eng.upload(ldescs)  # once per plan
+            self._out = None
         out = self.eng.decode_slices(params, local, ldescs, reader_flags=1,
                                      tier=TIER_T0, mb_capacity=self.mb_capacity,
-                                     d_descs=self.eng.upload(ldescs),
-                                     outputs=reuse)
+                                     d_descs=self._d_descs, outputs=self._out)
         self._out = out
         self.last_decode_ms = self.eng.last_kernel_ms("decode")
         return self.eng.download(out["results"], n * 64).reshape(n, 64)
@@ -254,6 +283,8 @@ class EngineOps:
         self.mb_capacity = mb_capacity
         self.last_decode_ms = 0.0
         self._out = None
+        self._desc_key = None
+        self._pack_cache = {}
 
     def sync(self):
         self.eng.sync()
@@ -293,26 +324,53 @@ class EngineOps:
         return bytes(stream[off:off + n].cpu().numpy())
 
     def pack(self, stream, offs, sizes, loffs, total):
-        """slices of the stream -> one packed buffer (device to device)"""
+        """slices of the stream -> one packed buffer, by the engine's gather
+        kernel (h264_amd_pack); the index arrays are uploaded once per plan"""
         if len(offs) == 0:
             return self.alloc(0)
-        views = [stream[int(o):int(o) + int(z)] for o, z in zip(offs, sizes)]
-        pad = self.torch.full((64,), 0xff, dtype=self.torch.uint8,
-                              device=self.gpu)
-        return self.torch.cat(views + [pad])
+        key = (len(offs), int(np.asarray(offs, dtype=np.uint64).sum()),
+               int(total))
+        idx = self._pack_cache.get(key)
+        if idx is None:
+            idx = (self.eng.upload(np.ascontiguousarray(offs, dtype=np.uint64)),
+                   self.eng.upload(np.ascontiguousarray(loffs, dtype=np.uint64)),
+                   self.eng.upload(np.ascontiguousarray(sizes, dtype=np.uint32)))
+            self._pack_cache = {key: idx}
+        out = self.alloc(total)
+        from .capi import engine_lib, _check
+        L = engine_lib()
+        L.h264_amd_pack.argtypes = [C.c_void_p] * 6 + [C.c_uint32]
+        _check(L.h264_amd_pack(self.eng.h, out.data_ptr(), stream.data_ptr(),
+                               idx[0].ptr, idx[1].ptr, idx[2].ptr, len(offs)),
+               "pack")
+        self.eng.sync()
+        return out
 
     def decode(self, params, local, ldescs):
         from .ctypes_abi import TIER_T0
+        from .capi import ExtBuf
         n = len(ldescs)
         if n == 0:
             return np.zeros((0, 64), dtype=np.uint8)
-        reuse = self._out if self._out and self._out["n"] == n else None
+        # descriptors go up once per plan, result records stay on the device
+        # (a torch tensor, so that RCCL can all-gather them from where they are)
+        key = (n, ldescs.tobytes())
+        if self._desc_key != key:
+            self._desc_key = key
+            self._d_descs = self.eng.upload(ldescs)
+            self._res = self.torch.empty(n * 64, dtype=self.torch.uint8,
+                                         device=self.gpu)
+            self._out = None
+        reuse = self._out
+        if reuse is None:
+            reuse = {"results": ExtBuf(self._res.data_ptr(), n * 64)}
         out = self.eng.decode_slices(params, self._ext(local), ldescs,
                                      reader_flags=1, tier=TIER_T0,
                                      mb_capacity=self.mb_capacity,
-                                     d_descs=self.eng.upload(ldescs),
-                                     outputs=reuse)
+                                     d_descs=self._d_descs, outputs=reuse)
         self._out = out
         self.last_decode_ms = self.eng.last_kernel_ms("decode")
-        raw = self.eng.download(out["results"], n * 64)
-        return raw.reshape(n, 64)
+        if self.staging:
+            return self._res.cpu().numpy().reshape(n, 64)
+        return self._res.view(n, 64)
+

@@ -109,7 +109,12 @@ def gather_records(dist, records, index, total, device="cpu"):
     """All-gather fixed-size per-slice records (uint8 array [n_local, width])
     into the batch's original order.  `index` holds the global slice index of
     every local record (from balance()).  Ranks may hold different counts."""
-    records = np.ascontiguousarray(records, dtype=np.uint8)
+    on_device = not isinstance(records, np.ndarray)  # a torch tensor
+    if on_device and dist is None:
+        records = records.cpu().numpy()
+        on_device = False
+    if not on_device:
+        records = np.ascontiguousarray(records, dtype=np.uint8)
     width = records.shape[1]
     if dist is None:
         out = np.zeros((total, width), dtype=np.uint8)
@@ -127,7 +132,10 @@ def gather_records(dist, records, index, total, device="cpu"):
     pad_rec = torch.zeros((cap, width), dtype=torch.uint8, device=device)
     pad_idx = torch.full((cap,), -1, dtype=torch.int64, device=device)
     if records.shape[0]:
-        pad_rec[:records.shape[0]] = torch.from_numpy(records).to(device)
+        # records decoded on the GPU stay there: no host round trip in front
+        # of the all-gather
+        pad_rec[:records.shape[0]] = records if on_device else \
+            torch.from_numpy(records).to(device)
         pad_idx[:records.shape[0]] = torch.from_numpy(
             np.asarray(index, dtype=np.int64)).to(device)
     all_rec = [torch.zeros_like(pad_rec) for _ in range(world)]

@@ -62,9 +62,10 @@ class OracleOps:
         return bytes(stream[off:off + n].numpy())
 
     def pack(self, stream, offs, sizes, loffs, total):
-        views = [stream[int(o):int(o) + int(z)] for o, z in zip(offs, sizes)]
-        return self.torch.cat(views + [self.torch.full(
-            (64,), 0xff, dtype=self.torch.uint8)])
+        out = self.torch.full((int(total) + 64,), 0xff, dtype=self.torch.uint8)
+        for o, z, l in zip(offs, sizes, loffs):
+            out[int(l):int(l) + int(z)] = stream[int(o):int(o) + int(z)]
+        return out
 
     def note_plan(self, plan, epochs_after):
         self.ps, self.epochs_after = plan.ps_nals, epochs_after
@@ -108,7 +109,10 @@ def main():
         data = streams.annexb(nals)
         stream = ops.upload(np.frombuffer(data, dtype=np.uint8))
     t0 = time.perf_counter()
-    table, plan = pipeline.run_step(dist, ops, stream, len(data), 256)
+    # min_per_rank 8: a 23-slice stream is spread over both ranks (the
+    # product's default of 1024 keeps anything that small on one)
+    table, plan = pipeline.run_step(dist, ops, stream, len(data), 256,
+                                    min_per_rank=8)
     dt = time.perf_counter() - t0
     time.sleep(0.05 * (rank + 1))  # ranks finish at different times
     dt2 = time.perf_counter() - t0
@@ -122,7 +126,9 @@ def main():
     received = [None] * world
     dist.all_gather_object(received, ops.bytes_received)
     if rank == 0:
-        parts = shard.balance(plan.descs["size"], world)
+        parts, used = pipeline.partition(plan.descs["size"], world, 8)
+        assert used == plan.ranks_used == 2
+        assert pipeline.partition(plan.descs["size"], world)[1] == 1
         print(json.dumps({
             "world": world, "slowest": slowest, "own": dt2, "step": dt,
             "slices": len(plan.descs),
