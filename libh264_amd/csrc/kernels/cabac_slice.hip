@@ -215,14 +215,17 @@ __device__ __forceinline__ void cs_refill(CbEng &c, WaveBits &wb)
 	}
 }
 
-/* 9.3.1.2 at the cursor */
-__device__ __forceinline__ void cs_start(CbEng &c, WaveBits &wb, uint32_t lane)
+/* 9.3.1.2 at the cursor.  False: codIOffset 510 or 511, which the standard
+ * forbids -- codIOffset < codIRange would never hold again and the scaled
+ * register would overflow; -EIO in oracle and product */
+__device__ __forceinline__ bool cs_start(CbEng &c, WaveBits &wb, uint32_t lane)
 {
 	wb_sync(wb, lane);
 	c.V = wb_peek(wb, lane);
 	wb_skip(wb, 32);
 	c.k = 23;
 	c.range = 510;
+	return (c.V >> 23) < 510u;
 }
 
 /* RBSP bits the arithmetic decoder has consumed (what a bit-serial decoder
@@ -519,9 +522,11 @@ cs_slice_data(CbEng &c, WaveBits &wb, CbCtx &x, uint8_t *stage, uint8_t *row,
 				return -EIO;
 		}
 	}
-	cs_start(c, wb, lane);
-	if (cs_eof(c, wb))
-		return -EIO;
+	{
+		const bool legal = cs_start(c, wb, lane);
+		if (cs_eof(c, wb) || !legal)
+			return -EIO;
+	}
 
 	CbLanes LN;
 	cs_lane_roles(LN, lane, S.cat);
@@ -722,7 +727,10 @@ cs_slice_data(CbEng &c, WaveBits &wb, CbCtx &x, uint8_t *stage, uint8_t *row,
 				wb_sync(wb, lane);
 				if (wb_overrun(wb))
 					return -EIO;
-				cs_start(c, wb, lane);
+				/* (a start past the end of the data is caught by the
+				 * test behind the macroblock: -EIO as well) */
+				if (!cs_start(c, wb, lane))
+					return -EIO;
 				mb_type = H264_MB_TYPE_I_PCM;
 				H = lane == 0 ? (mb_type | (flags << 16) | (raw << 24))
 				    : lane >= 4 && lane < 16 ? 0x10101010u

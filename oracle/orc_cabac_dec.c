@@ -89,7 +89,15 @@ struct cd {
 static int d_init(struct cd *c)
 {
 	c->range = 510;
-	return orc_bs_read_bits(c->bs, &c->offset, 9) < 0 ? -EIO : 0;
+	if (orc_bs_read_bits(c->bs, &c->offset, 9) < 0)
+		return -EIO;
+	/* 9.3.1.2: codIOffset 510 and 511 are illegal.  From a legal start
+	 * codIOffset < codIRange holds for good; from an illegal one it never
+	 * does again and codIOffset grows without bound -- an error here, in
+	 * oracle and product alike, instead of arithmetic on a state the
+	 * decoding engine is not defined for (the volume fuzz found the two
+	 * diverging there: the kernel keeps codIOffset scaled in one register) */
+	return c->offset >= c->range ? -EIO : 0;
 }
 
 static int d_renorm(struct cd *c)

@@ -127,3 +127,19 @@ def test_damaged_slices_end_defined():
                 nal[p] ^= 1 << rnd.randrange(8)
         r = orc.parse_nalus(head + [bytes(nal)], flags=FLAGS).results[0]
         assert r.status in (0, -5, -22, -38, -75, -2)
+
+
+def test_illegal_start_of_the_decoding_engine():
+    """codIOffset 510 / 511 at the start (9.3.1.2 forbids them): -EIO, not
+    arithmetic on a state the engine is not defined for (found by
+    tools/fuzz_cabac_full.py: oracle and kernel diverged there)"""
+    cfg = cabac_cfg()
+    nal = gen.slice_nal(cfg, cabac_slice(cfg, 3, 0))
+    r = orc.parse_nalus([gen.sps(cfg), gen.pps(cfg), nal],
+                        flags=FLAGS).results[0]
+    assert r.status == 0
+    bad = bytearray(nal)
+    bad[r.rawdata_off] = bad[r.rawdata_off + 1] = 0xff
+    r2 = orc.parse_nalus([gen.sps(cfg), gen.pps(cfg), bytes(bad)],
+                         flags=FLAGS).results[0]
+    assert (r2.status, r2.mb_count) == (-5, 0)
