@@ -81,6 +81,10 @@ struct h264_reader {
 	size_t d_buf_cap;
 	void *d_nals, *d_descs, *d_results, *d_headers, *d_mb;
 	size_t cap_nals, cap_descs, cap_results, cap_headers, cap_mb;
+	/* one slice decoded again with more room (retry_big_slice): buffers of
+	 * its own, the launch's results stay on the device for later pages */
+	void *d_retry, *d_retry_mb;
+	size_t cap_retry, cap_retry_mb;
 	/* host images of one decoded chunk of slices */
 	struct h264_amd_slice_result *h_results;
 	struct h264_slice_header *h_headers;

@@ -8,8 +8,12 @@
  *   2. a host pre-pass walks the table, parses the parameter sets (a few bytes
  *      each) into the reader's versioned snapshot and tags every slice NAL
  *      with the epoch current at its position;
- *   3. ALL slice NAL units of the buffer are decoded by one
- *      h264_amd_decode_slices() launch per chunk -- one slice per wavefront;
+ *   3. ALL slice NAL units of the buffer are decoded by ONE
+ *      h264_amd_decode_slices() launch -- one slice per wavefront -- into
+ *      device buffers (up to RD_DEVICE_BYTES of records per launch: HBM is
+ *      large, nothing ties the launch to the host's page); the records come
+ *      to the host a page of RD_CHUNK_BYTES at a time as the replay reaches
+ *      them;
  *   4. the callbacks are replayed on the host in bitstream order from the
  *      kernel's records, together with the per-NAL context updates and the
  *      access-unit detection of 7.4.1.2.4, so that a callback observes the
@@ -20,7 +24,8 @@
  */
 #include "h264_priv.h"
 
-#define RD_CHUNK_BYTES ((size_t)64 << 20) /* host image of one chunk */
+#define RD_CHUNK_BYTES ((size_t)64 << 20) /* host image of one page of records */
+#define RD_DEVICE_BYTES ((size_t)8 << 30) /* records of one launch, on the device */
 #define RD_MAX_EPOCHS 1024 /* compact the snapshot beyond this */
 
 /* what the pre-pass decided for one NAL unit */
@@ -28,11 +33,13 @@ struct rd_plan {
 	int64_t slice; /* index into the slice batch or -1 */
 };
 
-/* one decoded chunk of the slice batch */
+/* the slice batch of one buffer: launches and host pages */
 struct rd_batch {
 	struct h264_amd_engine *eng;
 	size_t n; /* slices in the buffer */
-	size_t chunk_n; /* slices per chunk */
+	size_t launch_n; /* slices per launch (a multiple of chunk_n, or n) */
+	size_t llo, lhi; /* slices whose records are on the device: [llo, lhi) */
+	size_t chunk_n; /* slices per host page */
 	size_t lo, hi; /* slices currently on the host: [lo, hi) */
 	uint32_t tier, mb_cap, flags;
 };
@@ -69,7 +76,8 @@ int h264_reader_destroy(struct h264_reader *rd)
 		return 0;
 	if (rd->d_buf != NULL && h264_host_engine(&eng) == 0) {
 		void *d[] = {rd->d_buf,	    rd->d_nals,	   rd->d_descs,
-			     rd->d_results, rd->d_headers, rd->d_mb};
+			     rd->d_results, rd->d_headers, rd->d_mb,
+			     rd->d_retry,   rd->d_retry_mb};
 		h264_host_lock();
 		for (i = 0; i < H264_ARRAY_SIZE(d); i++) {
 			if (d[i] != NULL)
@@ -280,6 +288,19 @@ static int batch_setup(struct h264_reader *rd, struct rd_batch *b,
 		b->chunk_n = 1;
 	if (b->chunk_n > ns)
 		b->chunk_n = ns;
+	/* the launch: everything at once where the device has the room.  Slice
+	 * group maps stay with the launch that built them and a callback may
+	 * launch again (a dump of the slice does): such streams are launched a
+	 * page at a time, maps fetched right behind the launch */
+	env = getenv("H264_AMD_READER_DEVICE_BYTES");
+	b->launch_n = (env != NULL && atol(env) > 0 ? (size_t)atol(env)
+						     : RD_DEVICE_BYTES) /
+		      per_slice;
+	if (h264_amd_params_has_slice_groups(rd->params) || b->launch_n < b->chunk_n)
+		b->launch_n = b->chunk_n;
+	b->launch_n -= b->launch_n % b->chunk_n;
+	if (b->launch_n > ns)
+		b->launch_n = ns;
 	res = h264_host_grow(&rd->d_descs, &rd->cap_descs, ns * sizeof(*descs));
 	if (res == 0)
 		res = h264_amd_upload(b->eng, rd->d_descs, descs,
@@ -305,28 +326,67 @@ static int fetch_maps(struct h264_reader *rd, struct h264_amd_engine *eng,
 					 pitch);
 }
 
-/* make slice `idx` available in the host images */
+/* make slice `idx` available in the host images: launch the part of the batch
+ * it belongs to unless its records are on the device already, then bring its
+ * page over */
 static int batch_fetch(struct h264_reader *rd, struct rd_batch *b, size_t idx)
 {
 	struct h264_amd_decode_args a;
-	size_t lo, cn, mb_bytes;
+	size_t lo, cn, mb_bytes, off;
 	int res;
 	if (idx >= b->lo && idx < b->hi)
 		return 0;
+	if (idx < b->llo || idx >= b->lhi) {
+		size_t llo = idx - idx % b->launch_n;
+		size_t ln = b->n - llo < b->launch_n ? b->n - llo : b->launch_n;
+		size_t lmb = b->tier == H264_AMD_TIER_T0 ? ln * b->mb_cap * 4 : 0;
+		res = h264_host_grow(&rd->d_results, &rd->cap_results,
+				     ln * sizeof(*rd->h_results));
+		if (res == 0)
+			res = h264_host_grow(&rd->d_headers, &rd->cap_headers,
+					     ln * sizeof(*rd->h_headers));
+		if (res == 0 && lmb)
+			res = h264_host_grow(&rd->d_mb, &rd->cap_mb, lmb);
+		if (res < 0)
+			return res;
+		memset(&a, 0, sizeof(a));
+		a.d_buf = rd->d_buf;
+		a.d_descs = (const struct h264_amd_slice_desc *)rd->d_descs + llo;
+		a.n = (uint32_t)ln;
+		a.reader_flags = b->flags;
+		a.tier = b->tier;
+		a.mb_capacity = b->mb_cap;
+		a.d_results = rd->d_results;
+		a.d_headers = rd->d_headers;
+		a.d_mb_out = lmb ? rd->d_mb : NULL;
+		a.mb_stride = lmb ? 4 : 0;
+		{
+			/* H264_AMD_DEVICES names several devices: the launch is
+			 * spread over the engine group (a small one stays on the
+			 * first device, see h264_amd_group_plan).  Slice group maps
+			 * live with the engine that built them: streams with slice
+			 * groups stay on one device. */
+			struct h264_amd_group *grp = h264_host_group();
+			if (grp != NULL &&
+			    !h264_amd_params_has_slice_groups(rd->params))
+				res = h264_amd_group_decode_slices(grp, rd->params, &a,
+								   NULL, NULL);
+			else
+				res = h264_amd_decode_slices(b->eng, rd->params, &a);
+		}
+		if (res < 0)
+			return res;
+		b->llo = llo;
+		b->lhi = llo + ln;
+		b->lo = b->hi = 0;
+	}
 	lo = idx - idx % b->chunk_n;
-	cn = b->n - lo < b->chunk_n ? b->n - lo : b->chunk_n;
+	cn = b->lhi - lo < b->chunk_n ? b->lhi - lo : b->chunk_n;
 	mb_bytes = b->tier == H264_AMD_TIER_T0 ? cn * b->mb_cap * 4 : 0;
+	off = lo - b->llo; /* first slice of the page within the launch */
 
-	res = h264_host_grow(&rd->d_results, &rd->cap_results,
-			     cn * sizeof(*rd->h_results));
-	if (res == 0)
-		res = h264_host_grow(&rd->d_headers, &rd->cap_headers,
-				     cn * sizeof(*rd->h_headers));
-	if (res == 0 && mb_bytes)
-		res = h264_host_grow(&rd->d_mb, &rd->cap_mb, mb_bytes);
-	if (res == 0)
-		res = host_grow((void **)&rd->h_results, &rd->hcap_results,
-				cn * sizeof(*rd->h_results));
+	res = host_grow((void **)&rd->h_results, &rd->hcap_results,
+			cn * sizeof(*rd->h_results));
 	if (res == 0)
 		res = host_grow((void **)&rd->h_headers, &rd->hcap_headers,
 				cn * sizeof(*rd->h_headers));
@@ -334,40 +394,22 @@ static int batch_fetch(struct h264_reader *rd, struct rd_batch *b, size_t idx)
 		res = host_grow((void **)&rd->h_mb, &rd->hcap_mb, mb_bytes);
 	if (res < 0)
 		return res;
-
-	memset(&a, 0, sizeof(a));
-	a.d_buf = rd->d_buf;
-	a.d_descs = (const struct h264_amd_slice_desc *)rd->d_descs + lo;
-	a.n = (uint32_t)cn;
-	a.reader_flags = b->flags;
-	a.tier = b->tier;
-	a.mb_capacity = b->mb_cap;
-	a.d_results = rd->d_results;
-	a.d_headers = rd->d_headers;
-	a.d_mb_out = mb_bytes ? rd->d_mb : NULL;
-	a.mb_stride = mb_bytes ? 4 : 0;
-	{
-		/* H264_AMD_DEVICES names several devices: the chunk is spread over
-		 * the engine group (a small one stays on the first device, see
-		 * h264_amd_group_plan).  Slice group maps live with the engine
-		 * that built them: streams with slice groups stay on one device. */
-		struct h264_amd_group *grp = h264_host_group();
-		if (grp != NULL && !h264_amd_params_has_slice_groups(rd->params))
-			res = h264_amd_group_decode_slices(grp, rd->params, &a, NULL,
-							   NULL);
-		else
-			res = h264_amd_decode_slices(b->eng, rd->params, &a);
-	}
+	res = h264_amd_download(b->eng, rd->h_results,
+				(const struct h264_amd_slice_result *)rd->d_results + off,
+				cn * sizeof(*rd->h_results));
 	if (res == 0)
-		res = h264_amd_download(b->eng, rd->h_results, rd->d_results,
-					cn * sizeof(*rd->h_results));
-	if (res == 0)
-		res = h264_amd_download(b->eng, rd->h_headers, rd->d_headers,
+		res = h264_amd_download(b->eng, rd->h_headers,
+					(const struct h264_slice_header *)rd->d_headers + off,
 					cn * sizeof(*rd->h_headers));
 	if (res == 0 && mb_bytes)
-		res = h264_amd_download(b->eng, rd->h_mb, rd->d_mb, mb_bytes);
-	if (res == 0)
+		res = h264_amd_download(b->eng, rd->h_mb,
+					(const uint8_t *)rd->d_mb + off * b->mb_cap * 4,
+					mb_bytes);
+	if (res == 0) {
+		/* maps: only built for streams with slice groups, which launch a
+		 * page at a time (off = 0) */
 		res = fetch_maps(rd, b->eng, cn, &rd->h_fmo, &rd->hcap_fmo);
+	}
 	if (res < 0)
 		return res;
 	b->lo = lo;
@@ -394,11 +436,13 @@ static int retry_big_slice(struct h264_reader *rd, struct rd_batch *b,
 		size_t mb_bytes;
 		cap = cap > RD_MAX_MB_CAP / 8 ? RD_MAX_MB_CAP : cap * 8;
 		mb_bytes = b->tier == H264_AMD_TIER_T0 ? (size_t)cap * 4 : 0;
-		if (mb_bytes) {
-			res = h264_host_grow(&rd->d_mb, &rd->cap_mb, mb_bytes);
-			if (res < 0)
-				return res;
-		}
+		res = h264_host_grow(&rd->d_retry, &rd->cap_retry,
+				     4096 + sizeof(struct h264_slice_header));
+		if (res == 0 && mb_bytes)
+			res = h264_host_grow(&rd->d_retry_mb, &rd->cap_retry_mb,
+					     mb_bytes);
+		if (res < 0)
+			return res;
 		memset(&a, 0, sizeof(a));
 		a.d_buf = rd->d_buf;
 		a.d_descs = (const struct h264_amd_slice_desc *)rd->d_descs + slice;
@@ -406,14 +450,13 @@ static int retry_big_slice(struct h264_reader *rd, struct rd_batch *b,
 		a.reader_flags = b->flags;
 		a.tier = b->tier;
 		a.mb_capacity = cap;
-		a.d_results = rd->d_results;
-		a.d_headers = rd->d_headers;
-		a.d_mb_out = mb_bytes ? rd->d_mb : NULL;
+		a.d_results = rd->d_retry;
+		a.d_headers = (struct h264_slice_header *)((uint8_t *)rd->d_retry + 4096);
+		a.d_mb_out = mb_bytes ? rd->d_retry_mb : NULL;
 		a.mb_stride = mb_bytes ? 4 : 0;
 		res = h264_amd_decode_slices(b->eng, rd->params, &a);
 		if (res == 0)
-			res = h264_amd_download(b->eng, r, rd->d_results,
-						sizeof(*r));
+			res = h264_amd_download(b->eng, r, rd->d_retry, sizeof(*r));
 		if (res < 0)
 			return res;
 	} while (r->status == H264_AMD_E_MB_OVERFLOW && cap < RD_MAX_MB_CAP);
@@ -427,7 +470,7 @@ static int retry_big_slice(struct h264_reader *rd, struct rd_batch *b,
 		size_t bytes = (size_t)r->mb_count * 4;
 		res = host_grow((void **)&rd->h_big, &rd->hcap_big, bytes);
 		if (res == 0)
-			res = h264_amd_download(b->eng, rd->h_big, rd->d_mb,
+			res = h264_amd_download(b->eng, rd->h_big, rd->d_retry_mb,
 						bytes);
 		if (res < 0)
 			return res;
