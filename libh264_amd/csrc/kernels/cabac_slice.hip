@@ -173,10 +173,11 @@ __device__ __forceinline__ uint32_t cb_hdr(const struct h264_slice_header *h,
 struct CbEng {
 	/* codIOffset << k | the next k bits of the stream; codIRange; k <= 23 */
 	uint32_t V, range, k;
-	/* per lane (= pStateIdx): rangeTabLPS[lane][0..3]; transIdxLPS | flip << 6
-	 * (flip: valMPS changes on an LPS in state 0); transIdxMPS; Table 9-43 by
-	 * levelListIdx */
-	uint32_t lps4, trl, trm, pos8;
+	/* per lane (= pStateIdx): rangeTabLPS[lane][0..3]; what an LPS / an MPS
+	 * changes in a state, as an XOR on pStateIdx | valMPS << 6 (lane ^
+	 * transIdxLPS[lane], with bit 6 in lane 0 where an LPS flips valMPS; lane ^
+	 * transIdxMPS[lane]); Table 9-43 by levelListIdx */
+	uint32_t lps4, xl, xm, pos8;
 };
 
 __device__ __forceinline__ uint32_t cs_rl(uint32_t v, uint32_t l)
@@ -198,6 +199,16 @@ __device__ __forceinline__ uint32_t cs_wl(uint32_t vec, uint32_t val, uint32_t l
 	return vec;
 }
 
+/* the decoding engine's registers are operands of the hand-written decision
+ * (scalar registers): where the optimiser has computed one on the vector side
+ * it comes back here, behind the rarer operations, not in front of every bin */
+__device__ __forceinline__ void cs_pin(CbEng &c)
+{
+	c.V = (uint32_t)__builtin_amdgcn_readfirstlane((int)c.V);
+	c.range = (uint32_t)__builtin_amdgcn_readfirstlane((int)c.range);
+	c.k = (uint32_t)__builtin_amdgcn_readfirstlane((int)c.k);
+}
+
 /* 16 more bits of read-ahead; the window slides 32 bits late so that the
  * cursor can step back by k (I_PCM, end position) without leaving it */
 __device__ __forceinline__ void cs_refill(CbEng &c, WaveBits &wb)
@@ -212,6 +223,7 @@ __device__ __forceinline__ void cs_refill(CbEng &c, WaveBits &wb)
 		wb_skip(wb, 16);
 		c.V = (c.V << 16) | (v >> 16);
 		c.k += 16u;
+		cs_pin(c);
 	}
 }
 
@@ -225,6 +237,7 @@ __device__ __forceinline__ bool cs_start(CbEng &c, WaveBits &wb, uint32_t lane)
 	wb_skip(wb, 32);
 	c.k = 23;
 	c.range = 510;
+	cs_pin(c);
 	return (c.V >> 23) < 510u;
 }
 
@@ -241,30 +254,72 @@ __device__ __forceinline__ bool cs_eof(const CbEng &c, const WaveBits &wb)
 	return wb_all_in(wb) && cs_pos(c, wb) > wb_total_bits(wb);
 }
 
-/* 9.3.3.2.1 DecodeDecision on the context in lane `slot` of `reg`.  A state is
- * pStateIdx | valMPS << 6 and serves as a lane select as it is: the hardware
- * looks at six bits (tools/probe/lane_probe.hip).  The rangeTabLPS column of
- * the current codIRange is extracted in all 64 lanes (one v_bfe), so that the
- * state picks its value with one v_readlane and nothing is left to shift on the
- * scalar side. */
+/* 9.3.3.2.1 DecodeDecision on the context in lane `slot` of `reg`; returns the
+ * bin in bit 0 (the caller looks at nothing else).
+ *
+ * Written out instruction by instruction: the kernel is bound by the ONE scalar
+ * unit of a compute unit (30 scalar-port instructions per bin in the compiler's
+ * version against 10 vector ones, profiles/r03_cabac_pmc*.json), and the
+ * compiler spends eight of them on turning the decision into a lane mask and
+ * back.  Here:
+ *   * a state is pStateIdx | valMPS << 6 and serves as a lane select as it is
+ *     (the hardware looks at six bits, tools/probe/lane_probe.hip);
+ *   * the rangeTabLPS column of the current codIRange is extracted in all 64
+ *     lanes at once (one v_bfe), the state picks its value with one v_readlane;
+ *   * "codIOffset >= codIRange - rLPS" is the BORROW of one s_sub_u32: the
+ *     three selects (offset, range, state change) hang on SCC, and the bin is
+ *     valMPS + borrow + 1 from an s_addc_u32;
+ *   * the next state is the old one XOR a table value (transIdx differences,
+ *     the valMPS flip of state 0 included): nothing to carry over;
+ *   * the five instructions between the two v_readlane are the four wait
+ *     states the second one needs (its lane select was written by the first).
+ * 18 scalar + 6 vector instructions; the refill test in front and the caller's
+ * branch make it 22 on the scalar port. */
 __device__ __forceinline__ uint32_t cs_dec(CbEng &c, WaveBits &wb, uint32_t &reg,
 					   uint32_t slot)
 {
 	cs_refill(c, wb);
-	const uint32_t col = (c.lps4 >> ((c.range >> 3) & 24u)) & 0xffu; /* per lane */
-	const uint32_t s = cs_rl(reg, slot);
-	const uint32_t rl = cs_rl(col, s);
-	const uint32_t tl = cs_rl(c.trl, s), tm = cs_rl(c.trm, s);
-	const uint32_t rm = c.range - rl;
-	const uint32_t T = rm << c.k;
-	const bool lps = c.V >= T;
-	c.V -= lps ? T : 0u;
-	c.range = lps ? rl : rm;
-	reg = cs_wl(reg, (lps ? tl : tm) ^ (s & 64u), slot);
-	const uint32_t n = (uint32_t)__builtin_clz(c.range) - 23u;
-	c.range <<= n;
-	c.k -= n;
-	return (s >> 6) ^ (lps ? 1u : 0u);
+	uint32_t st, rl, xa, xb, rm, t0, nm, bin, vcol;
+	/* (the engine state is kept on the scalar side by cs_pin() behind every
+	 * other operation on it) */
+	slot = (uint32_t)__builtin_amdgcn_readfirstlane((int)slot);
+	cs_pin(c);
+	/* the lane select travels in M0: `slot` may come straight out of a vector
+	 * instruction (v_readfirstlane), and a lane select written by one needs
+	 * four wait states the assembler does not see into this block to add */
+	asm volatile("s_mov_b32 m0, %[slot]\n\t"
+		     "s_nop 0\n\t"
+		     "v_readlane_b32 %[st], %[reg], m0\n\t"
+		     "s_lshr_b32 %[t0], %[range], 3\n\t"
+		     "s_and_b32 %[t0], %[t0], 24\n\t"
+		     "v_bfe_u32 %[vcol], %[lps4], %[t0], 8\n\t"
+		     "s_xor_b32 %[nm], %[st], 64\n\t"
+		     "s_lshr_b32 %[nm], %[nm], 6\n\t" /* !valMPS */
+		     "v_readlane_b32 %[rl], %[vcol], %[st]\n\t"
+		     "v_readlane_b32 %[xa], %[xl], %[st]\n\t"
+		     "v_readlane_b32 %[xb], %[xm], %[st]\n\t"
+		     "s_sub_u32 %[rm], %[range], %[rl]\n\t"
+		     "s_lshl_b32 %[t0], %[rm], %[k]\n\t"
+		     "s_sub_u32 %[t0], %[V], %[t0]\n\t" /* SCC: the MPS path */
+		     "s_cselect_b32 %[V], %[V], %[t0]\n\t"
+		     "s_cselect_b32 %[range], %[rm], %[rl]\n\t"
+		     "s_cselect_b32 %[xa], %[xb], %[xa]\n\t"
+		     "s_addc_u32 %[bin], %[nm], 0\n\t" /* bit 0: the bin */
+		     "s_xor_b32 %[xa], %[xa], %[st]\n\t"
+		     "v_writelane_b32 %[reg], %[xa], m0\n\t"
+		     "s_flbit_i32_b32 %[t0], %[range]\n\t"
+		     "s_sub_u32 %[t0], %[t0], 23\n\t"
+		     "s_lshl_b32 %[range], %[range], %[t0]\n\t"
+		     "s_sub_u32 %[k], %[k], %[t0]"
+		     : [V] "+s"(c.V), [range] "+s"(c.range), [k] "+s"(c.k),
+		       [reg] "+v"(reg), [st] "=&s"(st), [rl] "=&s"(rl),
+		       [xa] "=&s"(xa), [xb] "=&s"(xb), [rm] "=&s"(rm),
+		       [t0] "=&s"(t0), [nm] "=&s"(nm), [bin] "=&s"(bin),
+		       [vcol] "=&v"(vcol)
+		     : [slot] "s"(slot), [lps4] "v"(c.lps4), [xl] "v"(c.xl),
+		       [xm] "v"(c.xm)
+		     : "m0", "scc");
+	return bin & 1u;
 }
 
 /* 9.3.3.2.3 DecodeBypass */
@@ -275,6 +330,7 @@ __device__ __forceinline__ uint32_t cs_bypass(CbEng &c, WaveBits &wb)
 	const uint32_t T = c.range << c.k;
 	const bool b = c.V >= T;
 	c.V -= b ? T : 0u;
+	cs_pin(c);
 	return b ? 1u : 0u;
 }
 
@@ -288,6 +344,7 @@ __device__ __forceinline__ uint32_t cs_term(CbEng &c, WaveBits &wb)
 	const uint32_t n = (uint32_t)__builtin_clz(c.range) - 23u;
 	c.range <<= n;
 	c.k -= n;
+	cs_pin(c);
 	return 0;
 }
 
@@ -1474,8 +1531,9 @@ h264_amd_k_decode_cabac(cs_args a)
 			const uint8_t *q = &a.tab->range_lps[lane][0];
 			c.lps4 = (uint32_t)q[0] | ((uint32_t)q[1] << 8) |
 				 ((uint32_t)q[2] << 16) | ((uint32_t)q[3] << 24);
-			c.trl = (uint32_t)a.tab->next_lps[lane] | (lane == 0 ? 64u : 0u);
-			c.trm = (uint32_t)a.tab->next_mps[lane];
+			c.xl = (lane ^ (uint32_t)a.tab->next_lps[lane]) |
+			       (lane == 0 ? 64u : 0u);
+			c.xm = lane ^ (uint32_t)a.tab->next_mps[lane];
 			c.pos8 = a.dtab->pos8[S.field][lane];
 		}
 		status = cs_slice_data(c, wb, x, stage, row, o, lane, S,
