@@ -58,6 +58,27 @@ if [ -f tools/probe/issue_probe.hip ]; then
 		> "$out/issue_probe_build.log" 2>&1 && /tmp/issue_probe > "$out/issue_probe.log" 2>&1
 fi
 
+step "CABAC kernel on config 3 with real content"
+python3 tools/bench_cabac.py --slices 4096 --reps 5 > "$out/cabac_bench.json" 2> "$out/cabac_bench.err" || exit 1
+tail -c 400 "$out/cabac_bench.json"
+rocprofv3 --kernel-trace --stats --output-format csv -d "$out/cabac_stats" -- \
+	python3 tools/bench_cabac.py --slices 4096 --reps 5 > "$out/cabac_stats.log" 2>&1 || exit 1
+find "$out/cabac_stats" -name "*kernel_stats.csv" -exec cp {} "$out/cabac_kernel_stats.csv" \;
+for c in FETCH_SIZE WRITE_SIZE; do
+	rocprofv3 --kernel-trace --pmc $c --output-format csv -d "$out/cpmc_$c" -- \
+		python3 tools/bench_cabac.py --slices 4096 --reps 1 > "$out/cpmc_$c.log" 2>&1 || exit 1
+done
+cbytes=$(python3 -c "import json; d=json.loads(open('$out/cabac_bench.json').read().strip().splitlines()[-1]); print(int(round(d['mbit_per_s']*1e6/8*d['ms']/1e3)))")
+python3 tools/pmc_traffic.py "$out/cpmc_FETCH_SIZE" "$out/cpmc_WRITE_SIZE" "$cbytes" \
+	"$out/cabac_hbm_traffic.json" h264_amd_k_decode_cabac > "$out/cpmc_traffic.log" 2>&1 || cat "$out/cpmc_traffic.log"
+python3 tools/pmc_decode.py --cabac --slices 4096 --out /tmp/pmc_cabac_$tag > "$out/pmc_cabac.log" 2>&1 || exit 1
+tail -n 2 "$out/pmc_cabac.log"
+rm -rf "$out/cabac_stats" "$out"/cpmc_FETCH_SIZE "$out"/cpmc_WRITE_SIZE
+
+step "config 1 (dump tool) and config 4 at 1 GiB"
+python3 bench.py --workload c1 > "$out/bench_c1.json" 2> "$out/bench_c1.err" || exit 1
+python3 bench.py --workload c4 --mib 1024 --steps 3 --warmup 1 > "$out/bench_c4_1gib.json" 2> "$out/bench_c4_1gib.err" || exit 1
+
 step "drop-in latency per NAL unit"
 python3 tools/bench_dropin.py --per-nal > "$out/dropin_per_nal.json" 2> "$out/dropin_per_nal.err" || true
 

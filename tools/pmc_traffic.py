@@ -34,8 +34,13 @@ def values(d, counter):
 
 
 def main():
+    global KERNEL
     fdir, wdir, nbytes, out = sys.argv[1], sys.argv[2], int(sys.argv[3]), \
         sys.argv[4]
+    if len(sys.argv) > 5:
+        # another kernel of a 4096-slice T0 launch (the CABAC pass on
+        # tools/bench_cabac.py)
+        KERNEL = sys.argv[5]
     fetch, write = values(fdir, "FETCH_SIZE"), values(wdir, "WRITE_SIZE")
     n = min(len(fetch), len(write))
     if n == 0:
@@ -46,7 +51,8 @@ def main():
     doc = {
         "command": "rocprofv3 --kernel-trace --pmc <COUNTER> --output-format "
                    "csv -- python3 bench.py --steps 2 --warmup 0 --verify 0 "
-                   "--cpu-sample 16  (one counter per pass), "
+                   "--cpu-sample 16  (one counter per pass; "
+                   "tools/bench_cabac.py --reps 1 for the CABAC kernel), "
                    "tools/pmc_traffic.py",
         "kernel": KERNEL, "slices": 4096, "tier": "T0",
         "bytes_per_gpu": nbytes,

@@ -27,6 +27,12 @@ def main():
                      ("issue_probe.log", "issue_probe.txt"),
                      ("mix.log", "decode_mix.jsonl"),
                      ("dropin_per_nal.json", "dropin_per_nal.json"),
+                     ("cabac_bench.json", "cabac_bench.json"),
+                     ("cabac_kernel_stats.csv", "cabac_kernel_stats.csv"),
+                     ("cabac_hbm_traffic.json", "cabac_hbm_traffic.json"),
+                     ("pmc_cabac.log", "cabac_pmc.json"),
+                     ("bench_c1.json", "bench_c1.json"),
+                     ("bench_c4_1gib.json", "bench_c4_1gib.json"),
                      ("phase_512.log", "decode_phase_timers_final.txt")]:
         if os.path.exists(os.path.join(g, src)):
             shutil.copy(os.path.join(g, src),
