@@ -170,11 +170,17 @@ __device__ __forceinline__ uint32_t cb_hdr(const struct h264_slice_header *h,
 }
 
 /* ---- decoding engine (9.3.1.2, 9.3.3.2), wave-uniform ------------------------ */
+#define CS_AL 23u /* codIRange and codIOffset sit in bits 31..23 */
 struct CbEng {
-	/* codIOffset << k | the next k bits of the stream; codIRange; k <= 23 */
-	uint32_t V, range, k;
+	/* O: codIOffset << 23 | up to 22 bits of the stream read ahead | a
+	 * sentinel 1 behind the last of them (zeros below);  R: codIRange << 23.
+	 * Both top-aligned: "codIOffset >= codIRange - rLPS" is one 32-bit
+	 * subtraction without a shift by the read-ahead count, the
+	 * renormalisation shift is s_flbit(R) itself, and there is no counter to
+	 * keep: the sentinel's position says how many bits are left */
+	uint32_t O, R;
 	/* per lane (= pStateIdx): rangeTabLPS[lane][0..3]; what an LPS / an MPS
-	 * changes in a state, as an XOR on pStateIdx | valMPS << 6 (lane ^
+	 * changes in a state, as an XOR on pStateIdx | !valMPS << 6 (lane ^
 	 * transIdxLPS[lane], with bit 6 in lane 0 where an LPS flips valMPS; lane ^
 	 * transIdxMPS[lane]); Table 9-43 by levelListIdx */
 	uint32_t lps4, xl, xm, pos8;
@@ -204,16 +210,23 @@ __device__ __forceinline__ uint32_t cs_wl(uint32_t vec, uint32_t val, uint32_t l
  * it comes back here, behind the rarer operations, not in front of every bin */
 __device__ __forceinline__ void cs_pin(CbEng &c)
 {
-	c.V = (uint32_t)__builtin_amdgcn_readfirstlane((int)c.V);
-	c.range = (uint32_t)__builtin_amdgcn_readfirstlane((int)c.range);
-	c.k = (uint32_t)__builtin_amdgcn_readfirstlane((int)c.k);
+	c.O = (uint32_t)__builtin_amdgcn_readfirstlane((int)c.O);
+	c.R = (uint32_t)__builtin_amdgcn_readfirstlane((int)c.R);
 }
 
-/* 16 more bits of read-ahead; the window slides 32 bits late so that the
- * cursor can step back by k (I_PCM, end position) without leaving it */
+/* bits read ahead of the arithmetic decoder */
+__device__ __forceinline__ uint32_t cs_ahead(const CbEng &c)
+{
+	return 22u - (uint32_t)__builtin_ctz(c.O);
+}
+
+/* 16 more bits of read-ahead when fewer than 6 are left (a decision shifts by
+ * at most 6: rangeTabLPS is 6 or more in every state a context can reach);
+ * the window slides 32 bits late so that the cursor can step back by the
+ * read-ahead (I_PCM, end position) without leaving it */
 __device__ __forceinline__ void cs_refill(CbEng &c, WaveBits &wb)
 {
-	if (__builtin_expect(c.k < 8u, 0)) {
+	if (__builtin_expect((c.O & 0x1ffffu) == 0u, 0)) {
 		if (__builtin_expect(wb.bitpos >= WB_SLIDE_BITS + 32u, 0)) {
 			wb.base += WB_SLIDE_BITS / 8u;
 			wb.bitpos -= WB_SLIDE_BITS;
@@ -221,31 +234,33 @@ __device__ __forceinline__ void cs_refill(CbEng &c, WaveBits &wb)
 		}
 		uint32_t v = wb_peek(wb, 0);
 		wb_skip(wb, 16);
-		c.V = (c.V << 16) | (v >> 16);
-		c.k += 16u;
+		/* the sentinel at bit s >= 17 becomes the first of 16 more bits,
+		 * the new sentinel sits at s - 16 */
+		const uint32_t s16 = (uint32_t)__builtin_ctz(c.O) - 16u;
+		c.O += (((v >> 15) | 1u) - 0x10000u) << s16;
 		cs_pin(c);
 	}
 }
 
 /* 9.3.1.2 at the cursor.  False: codIOffset 510 or 511, which the standard
- * forbids -- codIOffset < codIRange would never hold again and the scaled
- * register would overflow; -EIO in oracle and product */
+ * forbids -- codIOffset < codIRange would never hold again and the subtraction
+ * of the decision would wrap; -EIO in oracle and product */
 __device__ __forceinline__ bool cs_start(CbEng &c, WaveBits &wb, uint32_t lane)
 {
 	wb_sync(wb, lane);
-	c.V = wb_peek(wb, lane);
-	wb_skip(wb, 32);
-	c.k = 23;
-	c.range = 510;
+	const uint32_t v = wb_peek(wb, lane);
+	wb_skip(wb, 31);
+	c.O = v | 1u; /* 9 bits of offset, 22 read ahead, the sentinel */
+	c.R = 510u << CS_AL;
 	cs_pin(c);
-	return (c.V >> 23) < 510u;
+	return (v >> CS_AL) < 510u;
 }
 
 /* RBSP bits the arithmetic decoder has consumed (what a bit-serial decoder
  * would have read) */
 __device__ __forceinline__ uint32_t cs_pos(const CbEng &c, const WaveBits &wb)
 {
-	return wb_pos(wb) - c.k;
+	return wb_pos(wb) - cs_ahead(c);
 }
 
 /* a read went past the end of the NAL: the oracle's reader fails there */
@@ -257,24 +272,28 @@ __device__ __forceinline__ bool cs_eof(const CbEng &c, const WaveBits &wb)
 /* 9.3.3.2.1 DecodeDecision on the context in lane `slot` of `reg`; returns the
  * bin in bit 0 (the caller looks at nothing else).
  *
- * Written out instruction by instruction: the kernel is bound by the ONE scalar
- * unit of a compute unit (30 scalar-port instructions per bin in the compiler's
- * version against 10 vector ones, profiles/r03_cabac_pmc*.json), and the
- * compiler spends eight of them on turning the decision into a lane mask and
- * back.  Here:
- *   * a state is pStateIdx | valMPS << 6 and serves as a lane select as it is
+ * Written out instruction by instruction: the kernel is bound by the scalar
+ * unit (profiles/r03_cabac_pmc*.json: the time per bin is the scalar
+ * instructions per bin times the 4.6 cycles one costs with four waves per
+ * SIMD), and the compiler spends eight of them on turning the decision into a
+ * lane mask and back.  Here:
+ *   * a state is pStateIdx | !valMPS << 6 and serves as a lane select as it is
  *     (the hardware looks at six bits, tools/probe/lane_probe.hip);
- *   * the rangeTabLPS column of the current codIRange is extracted in all 64
- *     lanes at once (one v_bfe), the state picks its value with one v_readlane;
- *   * "codIOffset >= codIRange - rLPS" is the BORROW of one s_sub_u32: the
- *     three selects (offset, range, state change) hang on SCC, and the bin is
- *     valMPS + borrow + 1 from an s_addc_u32;
+ *   * the rangeTabLPS column of the current codIRange is picked in all 64
+ *     lanes at once (v_perm_b32 with codIRange's bits 8..6 as the selector: bit
+ *     8 is always set, so the selector is 4 + qCodIRangeIdx = "byte q of the
+ *     first source") and aligned (v_lshlrev), the state picks its row with
+ *     one v_readlane;
+ *   * "codIOffset >= codIRange - rLPS" is the BORROW of one s_sub_u32 on the
+ *     top-aligned registers: the three selects (offset, range, state change)
+ *     hang on SCC, and the bin is !valMPS + borrow from an s_addc_u32;
  *   * the next state is the old one XOR a table value (transIdx differences,
  *     the valMPS flip of state 0 included): nothing to carry over;
- *   * the five instructions between the two v_readlane are the four wait
- *     states the second one needs (its lane select was written by the first).
- * 18 scalar + 6 vector instructions; the refill test in front and the caller's
- * branch make it 22 on the scalar port. */
+ *   * renormalisation: s_flbit of the range IS the shift, for both registers;
+ *   * four instructions between the first v_readlane and the next are the
+ *     wait states that one needs (its lane select was written by the first).
+ * 14 scalar + 7 vector instructions (round 3's first assembly version: 18 + 6,
+ * the compiler's: 23 + 8). */
 __device__ __forceinline__ uint32_t cs_dec(CbEng &c, WaveBits &wb, uint32_t &reg,
 					   uint32_t slot)
 {
@@ -288,32 +307,28 @@ __device__ __forceinline__ uint32_t cs_dec(CbEng &c, WaveBits &wb, uint32_t &reg
 	 * instruction (v_readfirstlane), and a lane select written by one needs
 	 * four wait states the assembler does not see into this block to add */
 	asm volatile("s_mov_b32 m0, %[slot]\n\t"
-		     "s_nop 0\n\t"
+		     "s_bfe_u32 %[t0], %[R], 0x3001d\n\t" /* 4 + qCodIRangeIdx */
 		     "v_readlane_b32 %[st], %[reg], m0\n\t"
-		     "s_lshr_b32 %[t0], %[range], 3\n\t"
-		     "s_and_b32 %[t0], %[t0], 24\n\t"
-		     "v_bfe_u32 %[vcol], %[lps4], %[t0], 8\n\t"
-		     "s_xor_b32 %[nm], %[st], 64\n\t"
-		     "s_lshr_b32 %[nm], %[nm], 6\n\t" /* !valMPS */
+		     "v_perm_b32 %[vcol], %[lps4], 0, %[t0]\n\t"
+		     "v_lshlrev_b32 %[vcol], 23, %[vcol]\n\t"
+		     "s_lshr_b32 %[nm], %[st], 6\n\t" /* !valMPS */
+		     "s_nop 0\n\t"
 		     "v_readlane_b32 %[rl], %[vcol], %[st]\n\t"
 		     "v_readlane_b32 %[xa], %[xl], %[st]\n\t"
 		     "v_readlane_b32 %[xb], %[xm], %[st]\n\t"
-		     "s_sub_u32 %[rm], %[range], %[rl]\n\t"
-		     "s_lshl_b32 %[t0], %[rm], %[k]\n\t"
-		     "s_sub_u32 %[t0], %[V], %[t0]\n\t" /* SCC: the MPS path */
-		     "s_cselect_b32 %[V], %[V], %[t0]\n\t"
-		     "s_cselect_b32 %[range], %[rm], %[rl]\n\t"
+		     "s_sub_u32 %[rm], %[R], %[rl]\n\t"
+		     "s_sub_u32 %[t0], %[O], %[rm]\n\t" /* SCC: the MPS path */
+		     "s_cselect_b32 %[O], %[O], %[t0]\n\t"
+		     "s_cselect_b32 %[R], %[rm], %[rl]\n\t"
 		     "s_cselect_b32 %[xa], %[xb], %[xa]\n\t"
 		     "s_addc_u32 %[bin], %[nm], 0\n\t" /* bit 0: the bin */
 		     "s_xor_b32 %[xa], %[xa], %[st]\n\t"
 		     "v_writelane_b32 %[reg], %[xa], m0\n\t"
-		     "s_flbit_i32_b32 %[t0], %[range]\n\t"
-		     "s_sub_u32 %[t0], %[t0], 23\n\t"
-		     "s_lshl_b32 %[range], %[range], %[t0]\n\t"
-		     "s_sub_u32 %[k], %[k], %[t0]"
-		     : [V] "+s"(c.V), [range] "+s"(c.range), [k] "+s"(c.k),
-		       [reg] "+v"(reg), [st] "=&s"(st), [rl] "=&s"(rl),
-		       [xa] "=&s"(xa), [xb] "=&s"(xb), [rm] "=&s"(rm),
+		     "s_flbit_i32_b32 %[t0], %[R]\n\t"
+		     "s_lshl_b32 %[R], %[R], %[t0]\n\t"
+		     "s_lshl_b32 %[O], %[O], %[t0]"
+		     : [O] "+s"(c.O), [R] "+s"(c.R), [reg] "+v"(reg), [st] "=&s"(st),
+		       [rl] "=&s"(rl), [xa] "=&s"(xa), [xb] "=&s"(xb), [rm] "=&s"(rm),
 		       [t0] "=&s"(t0), [nm] "=&s"(nm), [bin] "=&s"(bin),
 		       [vcol] "=&v"(vcol)
 		     : [slot] "s"(slot), [lps4] "v"(c.lps4), [xl] "v"(c.xl),
@@ -322,14 +337,14 @@ __device__ __forceinline__ uint32_t cs_dec(CbEng &c, WaveBits &wb, uint32_t &reg
 	return bin & 1u;
 }
 
-/* 9.3.3.2.3 DecodeBypass */
+/* 9.3.3.2.3 DecodeBypass: 2 * codIOffset + bit against codIRange is O against
+ * R / 2 (exact: R has 23 zero bits), then O moves up */
 __device__ __forceinline__ uint32_t cs_bypass(CbEng &c, WaveBits &wb)
 {
 	cs_refill(c, wb);
-	c.k -= 1u;
-	const uint32_t T = c.range << c.k;
-	const bool b = c.V >= T;
-	c.V -= b ? T : 0u;
+	const uint32_t T = c.R >> 1;
+	const bool b = c.O >= T;
+	c.O = (c.O - (b ? T : 0u)) << 1;
 	cs_pin(c);
 	return b ? 1u : 0u;
 }
@@ -338,12 +353,12 @@ __device__ __forceinline__ uint32_t cs_bypass(CbEng &c, WaveBits &wb)
 __device__ __forceinline__ uint32_t cs_term(CbEng &c, WaveBits &wb)
 {
 	cs_refill(c, wb);
-	c.range -= 2u;
-	if (c.V >= (c.range << c.k))
+	c.R -= 2u << CS_AL;
+	if (c.O >= c.R)
 		return 1;
-	const uint32_t n = (uint32_t)__builtin_clz(c.range) - 23u;
-	c.range <<= n;
-	c.k -= n;
+	const uint32_t n = (uint32_t)__builtin_clz(c.R);
+	c.R <<= n;
+	c.O <<= n;
 	cs_pin(c);
 	return 0;
 }
@@ -512,9 +527,15 @@ cs_block(CbEng &c, WaveBits &wb, uint32_t &sreg, uint32_t &lreg, uint32_t &areg,
 	/* positions with a coefficient: 64 bits only where a block has them */
 	typedef typename std::conditional<IS8, uint64_t, uint32_t>::type mask_t;
 	mask_t sig = 0;
-	uint32_t i = 0;
-	bool last = false;
-	for (; i + 1u < numc; i++) {
+	const uint32_t nm1 = numc - 1u;
+	/* (no "last" flag carried out of the loop: the compiler turns one into
+	 * 64-bit lane masks and four scalar instructions per bin) */
+	for (uint32_t i = 0;; i++) {
+		if (i >= nm1) {
+			/* the last coefficient is inferred */
+			sig |= (mask_t)1 << nm1;
+			break;
+		}
 		uint32_t si, li;
 		if (IS8) {
 			const uint32_t p = cs_rl(c.pos8, i);
@@ -528,14 +549,10 @@ cs_block(CbEng &c, WaveBits &wb, uint32_t &sreg, uint32_t &lreg, uint32_t &areg,
 		}
 		if (cs_dec(c, wb, sreg, si)) {
 			sig |= (mask_t)1 << i;
-			if (cs_dec(c, wb, lreg, li)) {
-				last = true;
+			if (cs_dec(c, wb, lreg, li))
 				break;
-			}
 		}
 	}
-	if (!last)
-		sig |= (mask_t)1 << (numc - 1u);
 	uint32_t coef = 0, eq1 = 0, gt1 = 0;
 	while (sig) {
 		const uint32_t p = IS8 ? 63u - (uint32_t)__builtin_clzll(sig)
@@ -749,7 +766,7 @@ cs_slice_data(CbEng &c, WaveBits &wb, CbCtx &x, uint8_t *stage, uint8_t *row,
 				 * fresh start of the decoding engine (9.3.1.2) ---- */
 				if (cs_eof(c, wb))
 					return -EIO;
-				wb.bitpos -= c.k; /* hand the read-ahead back */
+				wb.bitpos -= cs_ahead(c); /* hand the read-ahead back */
 				uint32_t p = wb_pos(wb) & 7u;
 				if (p) {
 					if (wb_all_in(wb) &&
@@ -1487,8 +1504,8 @@ h264_amd_k_decode_cabac(cs_args a)
 	wb_open(wb, a.buf + d.offset, d.size, ring,
 		reinterpret_cast<uint32_t *>(lds + CS_STATE_OFF), lane);
 	CbEng c;
-	c.V = c.k = 0;
-	c.range = 510;
+	c.O = 1;
+	c.R = 510u << CS_AL;
 	if (status == 0) {
 		/* to the end of the slice header, where the first kernel stopped */
 		uint32_t left = r.end_bit;
@@ -1513,9 +1530,10 @@ h264_amd_k_decode_cabac(cs_args a)
 				uint32_t s = cabac_state_init(r.slice_qp,
 							      mn[8u * cj + 2u * col],
 							      mn[8u * cj + 2u * col + 1u]);
-				/* pStateIdx | valMPS << 6 */
-				s = (s & 63u) | ((s >> 8) << 6);
-				regs[q] = valid && ci < 1024u ? s : 0u;
+				/* pStateIdx | !valMPS << 6 (cs_dec) */
+				s = (s & 63u) | (((s >> 8) ^ 1u) << 6);
+				/* (cabac_init_idc > 2: all states 0, valMPS 0) */
+				regs[q] = valid && ci < 1024u ? s : 64u;
 			}
 			x.mb0 = regs[CX_MB0];
 			x.mb1 = regs[CX_MB1];

@@ -36,6 +36,10 @@ def main():
     ap.add_argument("--cabac", action="store_true",
                     help="the CABAC kernel on tools/bench_cabac.py's slices; "
                          "values per BIN instead of per macroblock")
+    ap.add_argument("--counters", default="",
+                    help="comma-separated counters of one extra pass instead "
+                         "of the two standard groups (e.g. SQC_ICACHE_REQ,"
+                         "SQC_ICACHE_HITS,SQC_ICACHE_MISSES)")
     ap.add_argument("--mix", default="",
                     help="a macroblock mix of tools/bench_mix.py instead of the "
                          "bench batch")
@@ -44,7 +48,8 @@ def main():
     if args.lib:
         env["H264_AMD_ENGINE_LIB"] = os.path.abspath(args.lib)
     res = {}
-    for gi, grp in enumerate(GROUPS):
+    groups = [args.counters.split(",")] if args.counters else GROUPS
+    for gi, grp in enumerate(groups):
         d = "%s_%d" % (args.out, gi)
         subprocess.run(["rm", "-rf", d])
         prog = [os.path.join(ROOT, "tools", "ab_decode.py"), "--child",
