@@ -224,9 +224,16 @@ __device__ __forceinline__ uint32_t cs_ahead(const CbEng &c)
  * at most 6: rangeTabLPS is 6 or more in every state a context can reach);
  * the window slides 32 bits late so that the cursor can step back by the
  * read-ahead (I_PCM, end position) without leaving it */
+__device__ __forceinline__ void cs_refill_now(CbEng &c, WaveBits &wb);
 __device__ __forceinline__ void cs_refill(CbEng &c, WaveBits &wb)
 {
-	if (__builtin_expect((c.O & 0x1ffffu) == 0u, 0)) {
+	if (__builtin_expect((c.O & 0x1ffffu) == 0u, 0))
+		cs_refill_now(c, wb);
+}
+
+__device__ __forceinline__ void cs_refill_now(CbEng &c, WaveBits &wb)
+{
+	{
 		if (__builtin_expect(wb.bitpos >= WB_SLIDE_BITS + 32u, 0)) {
 			wb.base += WB_SLIDE_BITS / 8u;
 			wb.bitpos -= WB_SLIDE_BITS;
@@ -269,6 +276,40 @@ __device__ __forceinline__ bool cs_eof(const CbEng &c, const WaveBits &wb)
 	return wb_all_in(wb) && cs_pos(c, wb) > wb_total_bits(wb);
 }
 
+/* DecodeDecision behind "v_readlane st, reg, m0": 9 scalar + 12 vector
+ * instructions.  The scalar unit is the one the kernel waits for, the vector
+ * ports have room (profiles/r03_cabac_pmc.json), so what can be computed for
+ * all 64 states at once is: the rangeTabLPS column of the current range
+ * (selector 4 + qCodIRangeIdx = range bits 8..6, v_perm_b32), aligned, and
+ * codIRange - rLPS for every state; the state then picks rLPS and the MPS range
+ * with one v_readlane each.  !valMPS comes through the vector side too (the
+ * whole register shifted, one lane read).  The four vector instructions in
+ * front are also the wait states the v_readlane by `st` needs (its lane select
+ * was written by the v_readlane before).  REG: the register operand holding the
+ * context, written with the new state */
+#define CS_DEC_TAIL(REG)                                                        \
+	"v_lshrrev_b32 %[vcol], 29, %[R]\n\t" /* 4 + qCodIRangeIdx */            \
+	"v_perm_b32 %[vcol], %[lps4], 0, %[vcol]\n\t"                           \
+	"v_lshlrev_b32 %[vcol], 23, %[vcol]\n\t"                                \
+	"v_sub_u32 %[vrm], %[R], %[vcol]\n\t"                                   \
+	"v_lshrrev_b32 %[vnm], 6, " REG "\n\t"                                  \
+	"v_readlane_b32 %[rl], %[vcol], %[st]\n\t"                              \
+	"v_readlane_b32 %[rm], %[vrm], %[st]\n\t"                               \
+	"v_readlane_b32 %[xa], %[xl], %[st]\n\t"                                \
+	"v_readlane_b32 %[xb], %[xm], %[st]\n\t"                                \
+	"v_readlane_b32 %[nm], %[vnm], m0\n\t" /* !valMPS */                     \
+	"s_sub_u32 %[t0], %[O], %[rm]\n\t" /* SCC: the MPS path */               \
+	"s_cselect_b32 %[O], %[O], %[t0]\n\t"                                   \
+	"s_cselect_b32 %[R], %[rm], %[rl]\n\t"                                  \
+	"s_cselect_b32 %[xa], %[xb], %[xa]\n\t"                                 \
+	"s_addc_u32 %[bin], %[nm], 0\n\t" /* bit 0: the bin */                   \
+	"s_xor_b32 %[xa], %[xa], %[st]\n\t"                                     \
+	"v_writelane_b32 " REG ", %[xa], m0\n\t"                                \
+	"s_flbit_i32_b32 %[t0], %[R]\n\t"                                       \
+	"s_lshl_b32 %[R], %[R], %[t0]\n\t"                                      \
+	"s_lshl_b32 %[O], %[O], %[t0]"
+#define CS_DEC_BODY CS_DEC_TAIL("%[reg]")
+
 /* 9.3.3.2.1 DecodeDecision on the context in lane `slot` of `reg`; returns the
  * bin in bit 0 (the caller looks at nothing else).
  *
@@ -291,14 +332,15 @@ __device__ __forceinline__ bool cs_eof(const CbEng &c, const WaveBits &wb)
  *     the valMPS flip of state 0 included): nothing to carry over;
  *   * renormalisation: s_flbit of the range IS the shift, for both registers;
  *   * four instructions between the first v_readlane and the next are the
- *     wait states that one needs (its lane select was written by the first).
- * 14 scalar + 7 vector instructions (round 3's first assembly version: 18 + 6,
- * the compiler's: 23 + 8). */
+ *     wait states that one needs (its lane select was written by the first);
+ *     M0 written by s_mov_b32 needs none in front of a v_readlane.
+ * 10 scalar + 13 vector instructions with the lane select (round 3's first
+ * assembly version: 18 + 6, the compiler's: 23 + 8). */
 __device__ __forceinline__ uint32_t cs_dec(CbEng &c, WaveBits &wb, uint32_t &reg,
 					   uint32_t slot)
 {
 	cs_refill(c, wb);
-	uint32_t st, rl, xa, xb, rm, t0, nm, bin, vcol;
+	uint32_t st, rl, xa, xb, rm, t0, nm, bin, vcol, vrm, vnm;
 	/* (the engine state is kept on the scalar side by cs_pin() behind every
 	 * other operation on it) */
 	slot = (uint32_t)__builtin_amdgcn_readfirstlane((int)slot);
@@ -307,30 +349,12 @@ __device__ __forceinline__ uint32_t cs_dec(CbEng &c, WaveBits &wb, uint32_t &reg
 	 * instruction (v_readfirstlane), and a lane select written by one needs
 	 * four wait states the assembler does not see into this block to add */
 	asm volatile("s_mov_b32 m0, %[slot]\n\t"
-		     "s_bfe_u32 %[t0], %[R], 0x3001d\n\t" /* 4 + qCodIRangeIdx */
 		     "v_readlane_b32 %[st], %[reg], m0\n\t"
-		     "v_perm_b32 %[vcol], %[lps4], 0, %[t0]\n\t"
-		     "v_lshlrev_b32 %[vcol], 23, %[vcol]\n\t"
-		     "s_lshr_b32 %[nm], %[st], 6\n\t" /* !valMPS */
-		     "s_nop 0\n\t"
-		     "v_readlane_b32 %[rl], %[vcol], %[st]\n\t"
-		     "v_readlane_b32 %[xa], %[xl], %[st]\n\t"
-		     "v_readlane_b32 %[xb], %[xm], %[st]\n\t"
-		     "s_sub_u32 %[rm], %[R], %[rl]\n\t"
-		     "s_sub_u32 %[t0], %[O], %[rm]\n\t" /* SCC: the MPS path */
-		     "s_cselect_b32 %[O], %[O], %[t0]\n\t"
-		     "s_cselect_b32 %[R], %[rm], %[rl]\n\t"
-		     "s_cselect_b32 %[xa], %[xb], %[xa]\n\t"
-		     "s_addc_u32 %[bin], %[nm], 0\n\t" /* bit 0: the bin */
-		     "s_xor_b32 %[xa], %[xa], %[st]\n\t"
-		     "v_writelane_b32 %[reg], %[xa], m0\n\t"
-		     "s_flbit_i32_b32 %[t0], %[R]\n\t"
-		     "s_lshl_b32 %[R], %[R], %[t0]\n\t"
-		     "s_lshl_b32 %[O], %[O], %[t0]"
+		     CS_DEC_BODY
 		     : [O] "+s"(c.O), [R] "+s"(c.R), [reg] "+v"(reg), [st] "=&s"(st),
 		       [rl] "=&s"(rl), [xa] "=&s"(xa), [xb] "=&s"(xb), [rm] "=&s"(rm),
 		       [t0] "=&s"(t0), [nm] "=&s"(nm), [bin] "=&s"(bin),
-		       [vcol] "=&v"(vcol)
+		       [vcol] "=&v"(vcol), [vrm] "=&v"(vrm), [vnm] "=&v"(vnm)
 		     : [slot] "s"(slot), [lps4] "v"(c.lps4), [xl] "v"(c.xl),
 		       [xm] "v"(c.xm)
 		     : "m0", "scc");
@@ -512,6 +536,150 @@ struct CbSlice {
 	uint32_t is_b, is_i, is_si;
 };
 
+/* ---- phase timers (diagnostic build only: -DCS_PHASE_TIMERS) -----------------
+ * tools/phase_timers.py --cabac: cycles (s_memtime) between consecutive marks,
+ * summed per phase in lane `phase` of one vector register, calls counted next
+ * to them; the sums replace the first 64 T0 words of the slice. */
+#ifdef CS_PHASE_TIMERS
+struct CsTimers {
+	uint32_t acc, cnt, lane; /* per lane */
+	uint32_t last; /* scalar */
+};
+#define CS_TARG , CsTimers &T
+#define CS_TPASS , T
+#define CS_T(k)                                                                \
+	do {                                                                   \
+		uint32_t t_ = (uint32_t)__builtin_readcyclecounter();          \
+		uint32_t d_ = t_ - T.last;                                     \
+		T.last = t_;                                                   \
+		T.acc += T.lane == (uint32_t)(k) ? d_ : 0u;                    \
+		T.cnt += T.lane == (uint32_t)(k) ? 1u : 0u;                    \
+	} while (0)
+#else
+#define CS_TARG
+#define CS_TPASS
+#define CS_T(k)                                                                \
+	do {                                                                   \
+	} while (0)
+#endif
+
+/* ---- a unary run (TU / U prefixes: coeff_abs_level_minus1, mvd, ref_idx,
+ * mb_qp_delta) -----------------------------------------------------------------
+ * Decisions on lane min(lane0 + k, cap) of `reg`, k = 0, 1, ..., until a bin is
+ * 0 or `maxn` bins were 1; returns the number of 1 bins.  The lane select
+ * stays in M0 between the bins; per bin 17 scalar instructions and three
+ * branches (a compiled loop around cs_dec(): 20 to 22 and three to five). */
+__device__ __forceinline__ uint32_t cs_run(CbEng &c, WaveBits &wb, uint32_t &reg,
+					   uint32_t lane0, uint32_t cap, uint32_t maxn)
+{
+	uint32_t st, rl, xa, xb, rm, t0, nm, bin, vcol, vrm, vnm, again;
+	uint32_t cnt = 0;
+	lane0 = (uint32_t)__builtin_amdgcn_readfirstlane((int)lane0);
+	cap = (uint32_t)__builtin_amdgcn_readfirstlane((int)cap);
+	maxn = (uint32_t)__builtin_amdgcn_readfirstlane((int)maxn);
+	for (;;) {
+		cs_pin(c);
+		asm volatile("s_mov_b32 m0, %[lane]\n"
+			     "1:\n\t"
+			     "s_and_b32 %[t0], %[O], 0x1ffff\n\t"
+			     "s_cbranch_scc0 8f\n\t"
+			     "v_readlane_b32 %[st], %[reg], m0\n\t"
+			     CS_DEC_TAIL("%[reg]") "\n\t"
+			     "s_bitcmp1_b32 %[bin], 0\n\t"
+			     "s_cbranch_scc0 6f\n\t"
+			     "s_add_u32 %[cnt], %[cnt], 1\n\t"
+			     "s_add_u32 m0, m0, 1\n\t"
+			     "s_min_u32 m0, m0, %[cap]\n\t"
+			     "s_cmp_lt_u32 %[cnt], %[maxn]\n\t"
+			     "s_cbranch_scc1 1b\n"
+			     "6:\n\t"
+			     "s_mov_b32 %[again], 0\n\t"
+			     "s_branch 7f\n"
+			     "8:\n\t"
+			     "s_mov_b32 %[again], 1\n"
+			     "7:\n\t"
+			     "s_mov_b32 %[lane], m0"
+			     : [O] "+s"(c.O), [R] "+s"(c.R), [reg] "+v"(reg),
+			       [lane] "+s"(lane0), [cnt] "+s"(cnt), [st] "=&s"(st),
+			       [rl] "=&s"(rl), [xa] "=&s"(xa), [xb] "=&s"(xb),
+			       [rm] "=&s"(rm), [t0] "=&s"(t0), [nm] "=&s"(nm),
+			       [bin] "=&s"(bin), [vcol] "=&v"(vcol), [vrm] "=&v"(vrm), [vnm] "=&v"(vnm),
+			       [again] "=&s"(again)
+			     : [cap] "s"(cap), [maxn] "s"(maxn), [lps4] "v"(c.lps4),
+			       [xl] "v"(c.xl), [xm] "v"(c.xm)
+			     : "m0", "scc");
+		if (!again)
+			return cnt;
+		cs_refill_now(c, wb);
+	}
+}
+
+/* ---- the significance map of a 4x4 block (7.3.5.3.3, first loop) ---------------
+ * significant_coeff_flag and last_significant_coeff_flag of coefficient i use
+ * the same ctxIdxInc (i), i.e. the same LANE of two registers: the lane select
+ * stays in M0 and counts up, nothing is set up per bin.  One pass of this block
+ * runs until the map is complete (0: a last flag was 1; 1: the coefficient
+ * before the final one was reached, the final one is inferred) or the
+ * read-ahead has to be topped up (2: in front of a significant_coeff_flag, 3:
+ * in front of a last_significant_coeff_flag; the caller refills and comes
+ * back with `phase` = reason - 2).  `sig` collects the significant positions
+ * by LANE (64 bits).  Per coefficient without a level: 16 scalar instructions
+ * and three branches (the compiler's loop around two cs_dec(): 22 and five). */
+__device__ __forceinline__ uint32_t cs_sigmap_run(CbEng &c, uint32_t &sreg,
+						  uint32_t &lreg, uint32_t &lane_io,
+						  uint32_t end_lane, uint32_t phase,
+						  uint64_t &sig)
+{
+	uint32_t st, rl, xa, xb, rm, t0, nm, bin, vcol, vrm, vnm, reason;
+	cs_pin(c);
+	lane_io = (uint32_t)__builtin_amdgcn_readfirstlane((int)lane_io);
+	end_lane = (uint32_t)__builtin_amdgcn_readfirstlane((int)end_lane);
+	phase = (uint32_t)__builtin_amdgcn_readfirstlane((int)phase);
+	asm volatile("s_mov_b32 m0, %[lane]\n\t"
+		     "s_cmp_lg_u32 %[phase], 0\n\t"
+		     "s_cbranch_scc1 3f\n"
+		     "1:\n\t" /* significant_coeff_flag */
+		     "s_and_b32 %[t0], %[O], 0x1ffff\n\t"
+		     "s_cbranch_scc0 8f\n\t"
+		     "v_readlane_b32 %[st], %[sreg], m0\n\t"
+		     CS_DEC_TAIL("%[sreg]") "\n\t"
+		     "s_bitcmp1_b32 %[bin], 0\n\t"
+		     "s_cbranch_scc0 5f\n\t"
+		     "s_bitset1_b64 %[sig], m0\n"
+		     "3:\n\t" /* last_significant_coeff_flag */
+		     "s_and_b32 %[t0], %[O], 0x1ffff\n\t"
+		     "s_cbranch_scc0 9f\n\t"
+		     "v_readlane_b32 %[st], %[lreg], m0\n\t"
+		     CS_DEC_TAIL("%[lreg]") "\n\t"
+		     "s_bitcmp1_b32 %[bin], 0\n\t"
+		     "s_cbranch_scc1 6f\n"
+		     "5:\n\t" /* next coefficient */
+		     "s_add_u32 m0, m0, 1\n\t"
+		     "s_cmp_lt_u32 m0, %[end]\n\t"
+		     "s_cbranch_scc1 1b\n\t"
+		     "s_mov_b32 %[reason], 1\n\t"
+		     "s_branch 7f\n"
+		     "6:\n\t"
+		     "s_mov_b32 %[reason], 0\n\t"
+		     "s_branch 7f\n"
+		     "8:\n\t"
+		     "s_mov_b32 %[reason], 2\n\t"
+		     "s_branch 7f\n"
+		     "9:\n\t"
+		     "s_mov_b32 %[reason], 3\n"
+		     "7:\n\t"
+		     "s_mov_b32 %[lane], m0"
+		     : [O] "+s"(c.O), [R] "+s"(c.R), [sreg] "+v"(sreg),
+		       [lreg] "+v"(lreg), [lane] "+s"(lane_io), [sig] "+s"(sig),
+		       [st] "=&s"(st), [rl] "=&s"(rl), [xa] "=&s"(xa), [xb] "=&s"(xb),
+		       [rm] "=&s"(rm), [t0] "=&s"(t0), [nm] "=&s"(nm),
+		       [bin] "=&s"(bin), [vcol] "=&v"(vcol), [vrm] "=&v"(vrm), [vnm] "=&v"(vnm), [reason] "=&s"(reason)
+		     : [end] "s"(end_lane), [phase] "s"(phase), [lps4] "v"(c.lps4),
+		       [xl] "v"(c.xl), [xm] "v"(c.xm)
+		     : "m0", "scc");
+	return reason;
+}
+
 /* ---- residual_block_cabac (7.3.5.3.3) ------------------------------------------
  * IS8: an 8x8 block (contexts by Table 9-43, all in the M8 register);
  * CDC: chroma DC (ctxIdxInc = Min(levelListIdx / NumC8x8, 2)).
@@ -522,12 +690,25 @@ struct CbSlice {
 template <bool IS8, bool CDC>
 __device__ __forceinline__ uint32_t
 cs_block(CbEng &c, WaveBits &wb, uint32_t &sreg, uint32_t &lreg, uint32_t &areg,
-	 uint32_t s_off, uint32_t a_off, uint32_t numc, uint32_t nc8, bool &ok)
+	 uint32_t s_off, uint32_t a_off, uint32_t numc, uint32_t nc8, bool &ok
+	 CS_TARG)
 {
 	/* positions with a coefficient: 64 bits only where a block has them */
 	typedef typename std::conditional<IS8, uint64_t, uint32_t>::type mask_t;
 	mask_t sig = 0;
 	const uint32_t nm1 = numc - 1u;
+	if (!IS8 && !CDC) {
+		uint64_t sl = 0;
+		uint32_t ln = s_off, phase = 0, why;
+		while ((why = cs_sigmap_run(c, sreg, lreg, ln, s_off + nm1, phase,
+					    sl)) >= 2u) {
+			phase = why - 2u;
+			cs_refill_now(c, wb);
+		}
+		sig = (mask_t)(sl >> s_off);
+		if (why == 1u)
+			sig |= (mask_t)1 << nm1; /* the last coefficient is inferred */
+	} else
 	/* (no "last" flag carried out of the loop: the compiler turns one into
 	 * 64-bit lane masks and four scalar instructions per bin) */
 	for (uint32_t i = 0;; i++) {
@@ -553,6 +734,7 @@ cs_block(CbEng &c, WaveBits &wb, uint32_t &sreg, uint32_t &lreg, uint32_t &areg,
 				break;
 		}
 	}
+	CS_T(12);
 	uint32_t coef = 0, eq1 = 0, gt1 = 0;
 	while (sig) {
 		const uint32_t p = IS8 ? 63u - (uint32_t)__builtin_clzll(sig)
@@ -563,9 +745,7 @@ cs_block(CbEng &c, WaveBits &wb, uint32_t &sreg, uint32_t &lreg, uint32_t &areg,
 			   a_off + (gt1 ? 0u : (eq1 < 3u ? 1u + eq1 : 4u)))) {
 			const uint32_t lim = CDC ? 3u : 4u;
 			const uint32_t cn = a_off + 5u + (gt1 < lim ? gt1 : lim);
-			a = 1;
-			while (a < 14u && cs_dec(c, wb, areg, cn))
-				a++;
+			a = 1u + cs_run(c, wb, areg, cn, cn, 13);
 			if (a == 14u)
 				a += cs_egk(c, wb, 0, ok);
 			gt1++;
@@ -576,6 +756,7 @@ cs_block(CbEng &c, WaveBits &wb, uint32_t &sreg, uint32_t &lreg, uint32_t &areg,
 		const uint32_t v = a + 1u;
 		coef = cs_wl(coef, (sgn ? 0u - v : v) & 0xffffu, p);
 	}
+	CS_T(13);
 	return coef;
 }
 
@@ -584,7 +765,7 @@ __device__ __forceinline__ int
 cs_slice_data(CbEng &c, WaveBits &wb, CbCtx &x, uint8_t *stage, uint8_t *row,
 	      OutCtx &o, uint32_t lane, const CbSlice &S, uint32_t first_mb,
 	      uint32_t mb_capacity, uint32_t &mb_count, uint32_t prio_slot,
-	      uint32_t prio_on)
+	      uint32_t prio_on CS_TARG)
 {
 	/* cabac_alignment_one_bit */
 	{
@@ -652,11 +833,13 @@ cs_slice_data(CbEng &c, WaveBits &wb, CbCtx &x, uint8_t *stage, uint8_t *row,
 		uint32_t me = CS_NB_VALID;
 		uint32_t skip = 0;
 
+		CS_T(0);
 		if (!S.is_i) {
 			/* mb_skip_flag: neighbour available and not skipped */
 			skip = cs_dec(c, wb, x.mb0,
 				      skip_ctx + (vA & ~nbA) + (vB & ~nbB));
 		}
+		CS_T(1);
 		if (skip) {
 			if (cs_eof(c, wb))
 				return -EIO;
@@ -665,6 +848,7 @@ cs_slice_data(CbEng &c, WaveBits &wb, CbCtx &x, uint8_t *stage, uint8_t *row,
 			prev_qpd_nz = 0;
 			G[0] = G[1] = G[2] = 0;
 			LL[0] = LL[1] = 0;
+			CS_T(2);
 		} else {
 			/* ---- macroblock_layer (7.3.5) ---- */
 			uint32_t raw = 0; /* mb_type as Tables 7-11 / 7-13 / 7-14 number it */
@@ -751,6 +935,7 @@ cs_slice_data(CbEng &c, WaveBits &wb, CbCtx &x, uint8_t *stage, uint8_t *row,
 				}
 			}
 
+			CS_T(3);
 			/* the record's head: dword j in lane j */
 			uint32_t H = 0;
 			uint32_t mb_type, cbp_luma = 0, cbp_chroma = 0, t8 = 0;
@@ -877,6 +1062,7 @@ cs_slice_data(CbEng &c, WaveBits &wb, CbCtx &x, uint8_t *stage, uint8_t *row,
 					LL[0] = LL[1] = 0;
 				}
 
+				CS_T(4);
 				if (!is_intra && nparts == 4) {
 					/* ---- sub_mb_pred (7.3.5.2) ---- */
 #pragma unroll
@@ -965,6 +1151,7 @@ cs_slice_data(CbEng &c, WaveBits &wb, CbCtx &x, uint8_t *stage, uint8_t *row,
 					me |= icp ? CS_NB_ICPNZ : 0u;
 				}
 				if (!is_intra && !direct16) {
+					CS_T(5);
 					/* ---- ref_idx (9.3.3.1.1.6), then mvd (9.3.3.1.1.7)
 					 * of the partitions, list 0 before list 1 ---- */
 #pragma unroll
@@ -994,13 +1181,12 @@ cs_slice_data(CbEng &c, WaveBits &wb, CbCtx &x, uint8_t *stage, uint8_t *row,
 							uint32_t v = 0;
 							if (cs_dec(c, wb, x.mb0,
 								   54u + (ra > 0) + 2u * (rb > 0))) {
-								v = 1;
-								uint32_t b = cs_dec(c, wb, x.mb0, 54 + 4);
-								while (b) {
-									if (++v > 255u)
-										return -EIO;
-									b = cs_dec(c, wb, x.mb0, 54 + 5);
-								}
+								/* bins on ctxIdx 58, then 59s; the
+								 * 255th 1 is one too many */
+								v = 1u + cs_run(c, wb, x.mb0, 54 + 4,
+										54 + 5, 255);
+								if (v > 255u)
+									return -EIO;
 							}
 							refw |= v << (8u * p);
 							const bool in =
@@ -1014,6 +1200,7 @@ cs_slice_data(CbEng &c, WaveBits &wb, CbCtx &x, uint8_t *stage, uint8_t *row,
 						else
 							refw0 = refw;
 					}
+					CS_T(6);
 #pragma unroll
 					for (uint32_t l = 0; l < 2; l++) {
 						for (uint32_t p = 0; p < nparts; p++) {
@@ -1061,12 +1248,9 @@ cs_slice_data(CbEng &c, WaveBits &wb, CbCtx &x, uint8_t *stage, uint8_t *row,
 										sum < 3u ? 0u : sum > 32u ? 2u : 1u;
 									uint32_t m = 0;
 									if (cs_dec(c, wb, x.mb0, off + inc)) {
-										m = 1;
-										while (m < 9u &&
-										       cs_dec(c, wb, x.mb0,
-											      off + (m < 4u ? m + 2u
-													    : 6u)))
-											m++;
+										/* ctxIdxInc 3, 4, 5, 6, 6, ... */
+										m = 1u + cs_run(c, wb, x.mb0, off + 3u,
+												off + 6u, 8);
 										if (m == 9u)
 											m += cs_egk(c, wb, 3, ok);
 									}
@@ -1088,8 +1272,10 @@ cs_slice_data(CbEng &c, WaveBits &wb, CbCtx &x, uint8_t *stage, uint8_t *row,
 							}
 						}
 					}
+					CS_T(7);
 				}
 
+				CS_T(8);
 				if (!i16) {
 					/* ---- coded_block_pattern (9.3.2.6, 9.3.3.1.1.4) ---- */
 					const uint32_t ca = nbA >> 8, cb = nbB >> 8;
@@ -1136,17 +1322,14 @@ cs_slice_data(CbEng &c, WaveBits &wb, CbCtx &x, uint8_t *stage, uint8_t *row,
 				uint32_t NZ = 0; /* lane b: nz_coeff[b] */
 				uint32_t dc = 0;
 
+				CS_T(9);
 				if (cbp || i16) {
 					/* ---- mb_qp_delta (9.3.2.7, 9.3.3.1.1.5) ---- */
 					uint32_t k = 0;
 					if (cs_dec(c, wb, x.mb0, 60u + prev_qpd_nz)) {
-						k = 1;
-						uint32_t b = cs_dec(c, wb, x.mb0, 60 + 2);
-						while (b) {
-							if (++k > 255u)
-								return -EIO;
-							b = cs_dec(c, wb, x.mb0, 60 + 3);
-						}
+						k = 1u + cs_run(c, wb, x.mb0, 60 + 2, 60 + 3, 255);
+						if (k > 255u)
+							return -EIO;
 					}
 					qpd = (k & 1u) ? (int32_t)((k + 1u) / 2u)
 						       : -(int32_t)(k / 2u);
@@ -1176,6 +1359,7 @@ cs_slice_data(CbEng &c, WaveBits &wb, CbCtx &x, uint8_t *stage, uint8_t *row,
 							G[q] = (LN.g_role & CS_ROLE_TOP) && !okB ? 0u : G[q];
 						}
 					}
+					CS_T(10);
 					for (uint32_t comp = 0; comp < ncomp; comp++) {
 						const uint32_t cbase = 256u * comp;
 						if (i16) {
@@ -1186,15 +1370,17 @@ cs_slice_data(CbEng &c, WaveBits &wb, CbCtx &x, uint8_t *stage, uint8_t *row,
 								vB ? (nbB >> (16u + comp)) & 1u : fill;
 							if (cs_dec(c, wb, x.m8[0],
 								   CXL_CBF + 0u + dA + 2u * dB)) {
+								CS_T(11);
 								uint32_t cf = cs_block<false, false>(
 									c, wb, x.sig[0], x.last[0],
-									x.abs[0], 0, 0, 16, 1, ok);
+									x.abs[0], 0, 0, 16, 1, ok CS_TPASS);
 								if (lane < 16u)
 									*reinterpret_cast<uint16_t *>(
 										stage + H264_AMD_T2_HEAD +
 										2u * (cbase + lane)) =
 										(uint16_t)cf;
 								dc |= 1u << comp;
+								CS_T(14);
 							}
 						}
 						if (t8) {
@@ -1212,9 +1398,10 @@ cs_slice_data(CbEng &c, WaveBits &wb, CbCtx &x, uint8_t *stage, uint8_t *row,
 											2u * cs_rl(G[0], cs_g5(x4, y4 - 1u)));
 								if (!coded)
 									continue;
+								CS_T(11);
 								uint32_t cf = cs_block<true, false>(
 									c, wb, x.m8[0], x.m8[0], x.abs[0],
-									0, CXL_ABS8, 64, 1, ok);
+									0, CXL_ABS8, 64, 1, ok CS_TPASS);
 								/* 4x4 view of the record: coefficient
 								 * 4 k + j is coefficient k of array j */
 								*reinterpret_cast<uint16_t *>(
@@ -1234,6 +1421,7 @@ cs_slice_data(CbEng &c, WaveBits &wb, CbCtx &x, uint8_t *stage, uint8_t *row,
 									lane == gl + 5u || lane == gl + 6u)
 									       ? 1u
 									       : G[0];
+								CS_T(14);
 							}
 						} else {
 							for (uint32_t b = 0; b < 16; b++) {
@@ -1248,15 +1436,16 @@ cs_slice_data(CbEng &c, WaveBits &wb, CbCtx &x, uint8_t *stage, uint8_t *row,
 								if (!cs_dec(c, wb, x.m8[0],
 									    CXL_CBF + (i16 ? 4u : 8u) + inc))
 									continue;
+								CS_T(11);
 								uint32_t cf;
 								if (i16)
 									cf = cs_block<false, false>(
 										c, wb, x.sig[0], x.last[0],
-										x.abs[0], 15, 10, 15, 1, ok);
+										x.abs[0], 15, 10, 15, 1, ok CS_TPASS);
 								else
 									cf = cs_block<false, false>(
 										c, wb, x.sig[0], x.last[0],
-										x.abs[0], 29, 20, 16, 1, ok);
+										x.abs[0], 29, 20, 16, 1, ok CS_TPASS);
 								const uint32_t numc = i16 ? 15u : 16u;
 								if (lane < numc)
 									*reinterpret_cast<uint16_t *>(
@@ -1270,6 +1459,7 @@ cs_slice_data(CbEng &c, WaveBits &wb, CbCtx &x, uint8_t *stage, uint8_t *row,
 											   (cf & 0xffffu) != 0)),
 									   16u * comp + b);
 								G[0] = lane == cs_g5(x4, y4) ? 1u : G[0];
+								CS_T(14);
 							}
 						}
 						if (c444) {
@@ -1293,15 +1483,17 @@ cs_slice_data(CbEng &c, WaveBits &wb, CbCtx &x, uint8_t *stage, uint8_t *row,
 								if (!cs_dec(c, wb, x.mb1,
 									    97 - 64 + dA + 2u * dB))
 									continue;
+								CS_T(11);
 								uint32_t cf = cs_block<false, true>(
 									c, wb, x.sig[0], x.last[0],
-									x.abs[0], 44, 30, nchroma, nc8, ok);
+									x.abs[0], 44, 30, nchroma, nc8, ok CS_TPASS);
 								if (lane < nchroma)
 									*reinterpret_cast<uint16_t *>(
 										stage + H264_AMD_T2_HEAD +
 										2u * (256u + nchroma * cc + lane)) =
 										(uint16_t)cf;
 								dc |= 2u << cc;
+								CS_T(14);
 							}
 						}
 						if (cbp_chroma & 2u) {
@@ -1317,9 +1509,10 @@ cs_slice_data(CbEng &c, WaveBits &wb, CbCtx &x, uint8_t *stage, uint8_t *row,
 									if (!cs_dec(c, wb, x.mb1,
 										    101 - 64 + inc))
 										continue;
+									CS_T(11);
 									uint32_t cf = cs_block<false, false>(
 										c, wb, x.sig[0], x.last[0],
-										x.abs[0], 47, 39, 15, 1, ok);
+										x.abs[0], 47, 39, 15, 1, ok CS_TPASS);
 									if (lane < 15u)
 										*reinterpret_cast<uint16_t *>(
 											stage + H264_AMD_T2_HEAD +
@@ -1333,6 +1526,7 @@ cs_slice_data(CbEng &c, WaveBits &wb, CbCtx &x, uint8_t *stage, uint8_t *row,
 												(cf & 0xffffu) != 0)),
 										16u * (1u + cc) + b);
 									G[0] = lane == gl ? 1u : G[0];
+									CS_T(14);
 								}
 							}
 						}
@@ -1349,6 +1543,7 @@ cs_slice_data(CbEng &c, WaveBits &wb, CbCtx &x, uint8_t *stage, uint8_t *row,
 				}
 				me |= dc << 16;
 
+				CS_T(15);
 				/* ---- the record ---- */
 				H = lane == 0 ? (mb_type | (cbp << 8) | (flags << 16) |
 						 (raw << 24))
@@ -1374,8 +1569,10 @@ cs_slice_data(CbEng &c, WaveBits &wb, CbCtx &x, uint8_t *stage, uint8_t *row,
 			}
 			if (cs_eof(c, wb))
 				return -EIO;
+			CS_T(16);
 			*reinterpret_cast<uint32_t *>(stage + 4u * lane) = H;
 			sd_emit_staged(o, stage, mbidx, lane);
+			CS_T(17);
 		}
 
 		/* what the next macroblocks look at: the row context of this
@@ -1407,9 +1604,12 @@ cs_slice_data(CbEng &c, WaveBits &wb, CbCtx &x, uint8_t *stage, uint8_t *row,
 			mbx = 0;
 		mbidx++;
 		mb_count = mbidx;
+		CS_T(18);
 		const uint32_t end = cs_term(c, wb); /* end_of_slice_flag */
 		if (cs_eof(c, wb))
 			return -EIO;
+		CS_T(19);
+		CS_T(20);
 		if (end)
 			break;
 	}
@@ -1503,6 +1703,12 @@ h264_amd_k_decode_cabac(cs_args a)
 	WaveBits wb;
 	wb_open(wb, a.buf + d.offset, d.size, ring,
 		reinterpret_cast<uint32_t *>(lds + CS_STATE_OFF), lane);
+#ifdef CS_PHASE_TIMERS
+	CsTimers T;
+	T.acc = T.cnt = 0;
+	T.lane = lane;
+	T.last = (uint32_t)__builtin_readcyclecounter();
+#endif
 	CbEng c;
 	c.O = 1;
 	c.R = 510u << CS_AL;
@@ -1557,7 +1763,7 @@ h264_amd_k_decode_cabac(cs_args a)
 		status = cs_slice_data(c, wb, x, stage, row, o, lane, S,
 				       r.first_mb_in_slice, a.mb_capacity, mb_count,
 				       a.prio_div ? (blockIdx.x / a.prio_div) & 3u : 0u,
-				       a.prio_div ? 1u : 0u);
+				       a.prio_div ? 1u : 0u CS_TPASS);
 	}
 
 	/* T0: flush the partial last group of 64 words */
@@ -1567,6 +1773,13 @@ h264_amd_k_decode_cabac(cs_args a)
 		uint32_t v = (uint32_t)__shfl((int)o.t0acc, (int)l);
 		*reinterpret_cast<uint32_t *>(o.mb_out + (size_t)(base + l) * o.mb_stride) = v;
 	}
+#ifdef CS_PHASE_TIMERS
+	if (o.tier == H264_AMD_TIER_T0 && mb_count >= 64u && lane < 32u) {
+		*reinterpret_cast<uint32_t *>(o.mb_out + (size_t)lane * o.mb_stride) = T.acc;
+		*reinterpret_cast<uint32_t *>(o.mb_out + (size_t)(32u + lane) * o.mb_stride) =
+			T.cnt;
+	}
+#endif
 	uint32_t lo = o.lo, hi = o.hi;
 #pragma unroll
 	for (int sft = 32; sft >= 1; sft >>= 1) {

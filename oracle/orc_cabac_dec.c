@@ -44,6 +44,9 @@
 #define EGK_MAX 24u /* prefix bits of an Exp-Golomb escape before -EIO */
 
 uint64_t orc_stat_cabac_bins;
+/* bins by kind (bench statistics): [ctxIdx] for decisions, [1024] bypass,
+ * [1025] terminate */
+uint64_t orc_stat_cabac_hist[1026];
 
 /* ---- constants ------------------------------------------------------------ */
 static uint8_t s_lps[64][4], s_next_lps[64], s_next_mps[64];
@@ -117,6 +120,7 @@ static int dd(struct cd *c, uint32_t ci, uint32_t *bin)
 	uint32_t q = (c->range >> 6) & 3;
 	uint32_t r_lps = s_lps[c->st[ci].idx][q];
 	orc_stat_cabac_bins++;
+	orc_stat_cabac_hist[ci & 1023u]++;
 	c->range -= r_lps;
 	if (c->offset >= c->range) {
 		*bin = !c->st[ci].mps;
@@ -136,6 +140,7 @@ static int d_bypass(struct cd *c, uint32_t *bin)
 {
 	uint32_t b = 0;
 	orc_stat_cabac_bins++;
+	orc_stat_cabac_hist[1024]++;
 	if (orc_bs_read_bits(c->bs, &b, 1) < 0)
 		return -EIO;
 	c->offset = (c->offset << 1) | b;
@@ -151,6 +156,7 @@ static int d_bypass(struct cd *c, uint32_t *bin)
 static int d_term(struct cd *c, uint32_t *bin)
 {
 	orc_stat_cabac_bins++;
+	orc_stat_cabac_hist[1025]++;
 	c->range -= 2;
 	if (c->offset >= c->range) {
 		*bin = 1;
