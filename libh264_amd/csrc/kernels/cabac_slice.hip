@@ -362,15 +362,22 @@ __device__ __forceinline__ uint32_t cs_dec(CbEng &c, WaveBits &wb, uint32_t &reg
 }
 
 /* 9.3.3.2.3 DecodeBypass: 2 * codIOffset + bit against codIRange is O against
- * R / 2 (exact: R has 23 zero bits), then O moves up */
+ * R / 2 (exact: R has 23 zero bits), then O moves up.  Five scalar
+ * instructions */
 __device__ __forceinline__ uint32_t cs_bypass(CbEng &c, WaveBits &wb)
 {
 	cs_refill(c, wb);
-	const uint32_t T = c.R >> 1;
-	const bool b = c.O >= T;
-	c.O = (c.O - (b ? T : 0u)) << 1;
 	cs_pin(c);
-	return b ? 1u : 0u;
+	uint32_t t, u, bin;
+	asm volatile("s_lshr_b32 %[t], %[R], 1\n\t"
+		     "s_sub_u32 %[u], %[O], %[t]\n\t" /* SCC: the bin is 0 */
+		     "s_cselect_b32 %[O], %[O], %[u]\n\t"
+		     "s_cselect_b32 %[bin], 0, 1\n\t"
+		     "s_lshl_b32 %[O], %[O], 1"
+		     : [O] "+s"(c.O), [t] "=&s"(t), [u] "=&s"(u), [bin] "=&s"(bin)
+		     : [R] "s"(c.R)
+		     : "scc");
+	return bin;
 }
 
 /* 9.3.3.2.2.3 DecodeTerminate */
@@ -387,22 +394,93 @@ __device__ __forceinline__ uint32_t cs_term(CbEng &c, WaveBits &wb)
 	return 0;
 }
 
+/* bypass bins that are 1, up to `maxn` of them and the 0 behind them (the
+ * prefix of an Exp-Golomb suffix); six scalar instructions per bin */
+__device__ __forceinline__ uint32_t cs_bypass_ones(CbEng &c, WaveBits &wb,
+						   uint32_t maxn)
+{
+	uint32_t n = 0, t, u, again;
+	maxn = (uint32_t)__builtin_amdgcn_readfirstlane((int)maxn);
+	for (;;) {
+		cs_pin(c);
+		asm volatile("1:\n\t"
+			     "s_and_b32 %[t], %[O], 0x1ffff\n\t"
+			     "s_cbranch_scc0 8f\n\t"
+			     "s_lshr_b32 %[t], %[R], 1\n\t"
+			     "s_sub_u32 %[u], %[O], %[t]\n\t"
+			     "s_cbranch_scc1 5f\n\t" /* a 0: done */
+			     "s_lshl_b32 %[O], %[u], 1\n\t"
+			     "s_add_u32 %[n], %[n], 1\n\t"
+			     "s_cmp_lt_u32 %[n], %[maxn]\n\t"
+			     "s_cbranch_scc1 1b\n\t"
+			     "s_mov_b32 %[again], 0\n\t"
+			     "s_branch 7f\n"
+			     "5:\n\t"
+			     "s_lshl_b32 %[O], %[O], 1\n\t"
+			     "s_mov_b32 %[again], 0\n\t"
+			     "s_branch 7f\n"
+			     "8:\n\t"
+			     "s_mov_b32 %[again], 1\n"
+			     "7:"
+			     : [O] "+s"(c.O), [n] "+s"(n), [t] "=&s"(t), [u] "=&s"(u),
+			       [again] "=&s"(again)
+			     : [R] "s"(c.R), [maxn] "s"(maxn)
+			     : "scc");
+		if (!again)
+			return n;
+		cs_refill_now(c, wb);
+	}
+}
+
+/* nb <= 31 bypass bins as a number, first bin in the highest place; seven
+ * scalar instructions per bin (the bins are collected inverted: the borrow of
+ * the compare is the carry of an s_addc) */
+__device__ __forceinline__ uint32_t cs_bypass_bits(CbEng &c, WaveBits &wb,
+						   uint32_t nb)
+{
+	if (nb == 0)
+		return 0;
+	uint32_t acc = 0, t, u, again;
+	uint32_t left = (uint32_t)__builtin_amdgcn_readfirstlane((int)nb);
+	for (;;) {
+		cs_pin(c);
+		asm volatile("1:\n\t"
+			     "s_and_b32 %[t], %[O], 0x1ffff\n\t"
+			     "s_cbranch_scc0 8f\n\t"
+			     "s_lshr_b32 %[t], %[R], 1\n\t"
+			     "s_sub_u32 %[u], %[O], %[t]\n\t" /* SCC: the bin is 0 */
+			     "s_cselect_b32 %[O], %[O], %[u]\n\t"
+			     "s_addc_u32 %[acc], %[acc], %[acc]\n\t"
+			     "s_lshl_b32 %[O], %[O], 1\n\t"
+			     "s_sub_u32 %[left], %[left], 1\n\t"
+			     "s_cmp_lg_u32 %[left], 0\n\t"
+			     "s_cbranch_scc1 1b\n\t"
+			     "s_mov_b32 %[again], 0\n\t"
+			     "s_branch 7f\n"
+			     "8:\n\t"
+			     "s_mov_b32 %[again], 1\n"
+			     "7:"
+			     : [O] "+s"(c.O), [acc] "+s"(acc), [left] "+s"(left),
+			       [t] "=&s"(t), [u] "=&s"(u), [again] "=&s"(again)
+			     : [R] "s"(c.R)
+			     : "scc");
+		if (!again)
+			return ~acc & ((1u << nb) - 1u);
+		cs_refill_now(c, wb);
+	}
+}
+
 /* suffix of UEGk (9.3.2.3); ok cleared after 24 prefix bits */
 __device__ __forceinline__ uint32_t cs_egk(CbEng &c, WaveBits &wb, uint32_t k,
 					   bool &ok)
 {
-	uint32_t v = 0, n = 0;
-	while (cs_bypass(c, wb)) {
-		v += 1u << k;
-		k++;
-		if (++n >= 24u) {
-			ok = false;
-			return 0;
-		}
+	const uint32_t p = cs_bypass_ones(c, wb, 24);
+	if (p >= 24u) {
+		ok = false;
+		return 0;
 	}
-	while (k--)
-		v += cs_bypass(c, wb) << k;
-	return v;
+	/* 2^k + 2^(k+1) + ... for the p ones, then k + p bits */
+	return (((1u << p) - 1u) << k) + cs_bypass_bits(c, wb, k + p);
 }
 
 /* ---- context registers -------------------------------------------------------- */
