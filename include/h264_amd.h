@@ -243,6 +243,18 @@ H264_API int h264_amd_download(struct h264_amd_engine *eng,
 			       void *dst,
 			       const void *d_src,
 			       size_t size);
+/* Page-locked host memory and a download that does not hold the caller (nor
+ * the engine's stream): the copy starts behind everything queued on the
+ * engine's stream so far and runs on a stream of its own;
+ * h264_amd_download_wait() returns when all such copies have landed.  What the
+ * drop-in reader fetches record pages with while it replays the callbacks of
+ * the page before (the reference has no counterpart: its parse and its
+ * callbacks are one loop, src/h264_reader.c:117-143). */
+H264_API int h264_amd_host_alloc(struct h264_amd_engine *eng, size_t size, void **ptr);
+H264_API int h264_amd_host_free(struct h264_amd_engine *eng, void *ptr);
+H264_API int h264_amd_download_async(struct h264_amd_engine *eng, void *dst,
+				     const void *d_src, size_t size);
+H264_API int h264_amd_download_wait(struct h264_amd_engine *eng);
 /* device to device, on the engine's stream */
 H264_API int h264_amd_copy(struct h264_amd_engine *e, void *d_dst,
 			   const void *d_src, size_t size);

@@ -91,6 +91,10 @@ struct h264_amd_engine {
 	uint32_t cu_count;
 	hipStream_t stream;
 	bool own_stream;
+	/* h264_amd_download_async(): copies that run behind the engine's work
+	 * without holding its stream */
+	hipStream_t copy_stream;
+	hipEvent_t copy_after;
 	dev_vlc_tables *d_vlc;
 	cabac_tables *d_cabac;
 	cabac_dec_tables *d_cabac_dec;
@@ -321,6 +325,10 @@ extern "C" int h264_amd_engine_destroy(struct h264_amd_engine *e)
 	hipFree(e->d_epochs);
 	scan_scratch_free(&e->scan);
 	hipFree(e->d_avcc_nals);
+	if (e->copy_stream != NULL) {
+		hipStreamDestroy(e->copy_stream);
+		hipEventDestroy(e->copy_after);
+	}
 	if (e->own_stream)
 		hipStreamDestroy(e->stream);
 	delete e;
@@ -376,6 +384,57 @@ extern "C" int h264_amd_download(struct h264_amd_engine *e, void *dst,
 		return -EINVAL;
 	HIP_TRY(hipMemcpyAsync(dst, d_src, size, hipMemcpyDeviceToHost, e->stream));
 	HIP_TRY(hipStreamSynchronize(e->stream));
+	return 0;
+}
+
+extern "C" int h264_amd_host_alloc(struct h264_amd_engine *e, size_t size, void **ptr)
+{
+	if (e == NULL || ptr == NULL)
+		return -EINVAL;
+	HIP_TRY(hipSetDevice(e->device));
+	*ptr = NULL;
+	if (hipHostMalloc(ptr, size ? size : 1, hipHostMallocDefault) != hipSuccess) {
+		(void)hipGetLastError();
+		*ptr = NULL;
+		return -ENOMEM;
+	}
+	return 0;
+}
+
+extern "C" int h264_amd_host_free(struct h264_amd_engine *e, void *ptr)
+{
+	if (e == NULL)
+		return -EINVAL;
+	if (ptr != NULL)
+		HIP_TRY(hipHostFree(ptr));
+	return 0;
+}
+
+extern "C" int h264_amd_download_async(struct h264_amd_engine *e, void *dst,
+				       const void *d_src, size_t size)
+{
+	if (e == NULL)
+		return -EINVAL;
+	HIP_TRY(hipSetDevice(e->device));
+	if (e->copy_stream == NULL) {
+		HIP_TRY(hipStreamCreateWithFlags(&e->copy_stream, hipStreamNonBlocking));
+		HIP_TRY(hipEventCreateWithFlags(&e->copy_after, hipEventDisableTiming));
+	}
+	/* behind everything queued on the engine's stream so far */
+	HIP_TRY(hipEventRecord(e->copy_after, e->stream));
+	HIP_TRY(hipStreamWaitEvent(e->copy_stream, e->copy_after, 0));
+	if (size)
+		HIP_TRY(hipMemcpyAsync(dst, d_src, size, hipMemcpyDeviceToHost,
+				       e->copy_stream));
+	return 0;
+}
+
+extern "C" int h264_amd_download_wait(struct h264_amd_engine *e)
+{
+	if (e == NULL)
+		return -EINVAL;
+	if (e->copy_stream != NULL)
+		HIP_TRY(hipStreamSynchronize(e->copy_stream));
 	return 0;
 }
 

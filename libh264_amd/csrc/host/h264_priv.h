@@ -85,12 +85,24 @@ struct h264_reader {
 	 * its own, the launch's results stay on the device for later pages */
 	void *d_retry, *d_retry_mb;
 	size_t cap_retry, cap_retry_mb;
-	/* host images of one decoded chunk of slices */
+	/* host images of one decoded chunk of slices: the page the replay reads
+	 * (h_results / h_headers / h_mb point into page[cur_page]) and the page
+	 * that is on its way from the device meanwhile; page-locked memory
+	 * where the runtime grants it */
+	struct rd_host_page {
+		struct h264_amd_slice_result *results;
+		struct h264_slice_header *headers;
+		uint32_t *mb;
+		size_t cap_results, cap_headers, cap_mb;
+		int pinned_results, pinned_headers, pinned_mb;
+	} page[2];
+	int cur_page;
+	double trace_wait_ms; /* H264_AMD_READER_TRACE */
 	struct h264_amd_slice_result *h_results;
 	struct h264_slice_header *h_headers;
 	uint32_t *h_mb;
 	uint32_t *h_big; /* one slice that outgrew the batch's mb_capacity */
-	size_t hcap_results, hcap_headers, hcap_mb, hcap_big;
+	size_t hcap_big;
 	/* slice group maps of the batch and of that one slice, fmo_pitch bytes
 	 * each (0: the launch built none) */
 	uint8_t *h_fmo, *h_fmo_big;

@@ -23,6 +23,25 @@
  * h264_reader_parse_nalu() on a slice return -ENODEV.
  */
 #include "h264_priv.h"
+#include <stdio.h>
+#include <time.h>
+
+/* H264_AMD_READER_TRACE=1: stage times of h264_reader_parse on stderr */
+static double rd_now(void)
+{
+	struct timespec ts;
+	clock_gettime(CLOCK_MONOTONIC, &ts);
+	return ts.tv_sec * 1e3 + ts.tv_nsec * 1e-6;
+}
+
+static int rd_trace(void)
+{
+	static int on = -1;
+	if (on < 0)
+		on = getenv("H264_AMD_READER_TRACE") != NULL;
+	return on;
+}
+
 
 #define RD_CHUNK_BYTES ((size_t)64 << 20) /* host image of one page of records */
 #define RD_DEVICE_BYTES ((size_t)8 << 30) /* records of one launch, on the device */
@@ -41,8 +60,111 @@ struct rd_batch {
 	size_t llo, lhi; /* slices whose records are on the device: [llo, lhi) */
 	size_t chunk_n; /* slices per host page */
 	size_t lo, hi; /* slices currently on the host: [lo, hi) */
+	size_t plo, phi; /* slices of the page in flight to the other host page */
 	uint32_t tier, mb_cap, flags;
 };
+
+/* one buffer of a host page: page-locked if the runtime gives it (the copy
+ * from the device then runs at link speed and truly beside the replay),
+ * plain memory otherwise */
+static int page_buf_grow(struct h264_amd_engine *eng, void **p, size_t *cap,
+			 int *pinned, size_t want)
+{
+	void *np = NULL;
+	if (want <= *cap && *p != NULL)
+		return 0;
+	if (*p != NULL) {
+		if (*pinned)
+			h264_amd_host_free(eng, *p);
+		else
+			free(*p);
+	}
+	*p = NULL;
+	*cap = 0;
+	*pinned = 0;
+	if (h264_amd_host_alloc(eng, want ? want : 1, &np) == 0 && np != NULL) {
+		*pinned = 1;
+	} else {
+		np = malloc(want ? want : 1);
+		if (np == NULL)
+			return -ENOMEM;
+	}
+	*p = np;
+	*cap = want;
+	return 0;
+}
+
+static int page_grow(struct h264_amd_engine *eng, struct rd_host_page *pg, size_t cn,
+		     size_t mb_bytes)
+{
+	int res = page_buf_grow(eng, (void **)&pg->results, &pg->cap_results,
+				&pg->pinned_results, cn * sizeof(*pg->results));
+	if (res == 0)
+		res = page_buf_grow(eng, (void **)&pg->headers, &pg->cap_headers,
+				    &pg->pinned_headers, cn * sizeof(*pg->headers));
+	if (res == 0 && mb_bytes)
+		res = page_buf_grow(eng, (void **)&pg->mb, &pg->cap_mb,
+				    &pg->pinned_mb, mb_bytes);
+	return res;
+}
+
+static void page_release(struct h264_reader *rd)
+{
+	struct h264_amd_engine *eng = NULL;
+	size_t i;
+	int have = 0;
+	for (i = 0; i < 2; i++)
+		have |= rd->page[i].pinned_results | rd->page[i].pinned_headers |
+			rd->page[i].pinned_mb;
+	if (have && h264_host_engine(&eng) < 0)
+		eng = NULL; /* (no device any more: the runtime went first) */
+	if (eng != NULL)
+		h264_amd_download_wait(eng);
+	for (i = 0; i < 2; i++) {
+		struct rd_host_page *pg = &rd->page[i];
+		void *ptr[3] = {pg->results, pg->headers, pg->mb};
+		int pin[3] = {pg->pinned_results, pg->pinned_headers, pg->pinned_mb};
+		size_t k;
+		for (k = 0; k < 3; k++) {
+			if (ptr[k] == NULL)
+				continue;
+			if (!pin[k])
+				free(ptr[k]);
+			else if (eng != NULL)
+				h264_amd_host_free(eng, ptr[k]);
+		}
+		memset(pg, 0, sizeof(*pg));
+	}
+	rd->h_results = NULL;
+	rd->h_headers = NULL;
+	rd->h_mb = NULL;
+}
+
+/* queue the copies of page [lo, lo + cn) of the launch into host page `pg` */
+static int page_start(struct h264_reader *rd, struct rd_batch *b,
+		      struct rd_host_page *pg, size_t lo, size_t cn)
+{
+	size_t mb_bytes = b->tier == H264_AMD_TIER_T0 ? cn * b->mb_cap * 4 : 0;
+	size_t off = lo - b->llo; /* first slice of the page within the launch */
+	int res = page_grow(b->eng, pg, cn, mb_bytes);
+	if (res < 0)
+		return res;
+	res = h264_amd_download_async(
+		b->eng, pg->results,
+		(const struct h264_amd_slice_result *)rd->d_results + off,
+		cn * sizeof(*pg->results));
+	if (res == 0)
+		res = h264_amd_download_async(
+			b->eng, pg->headers,
+			(const struct h264_slice_header *)rd->d_headers + off,
+			cn * sizeof(*pg->headers));
+	if (res == 0 && mb_bytes)
+		res = h264_amd_download_async(b->eng, pg->mb,
+					      (const uint8_t *)rd->d_mb +
+						      off * b->mb_cap * 4,
+					      mb_bytes);
+	return res;
+}
 
 int h264_reader_new(const struct h264_ctx_cbs *cbs, void *userdata,
 		    struct h264_reader **ret_obj)
@@ -87,9 +209,7 @@ int h264_reader_destroy(struct h264_reader *rd)
 	}
 	if (rd->params != NULL)
 		h264_amd_params_destroy(rd->params);
-	free(rd->h_results);
-	free(rd->h_headers);
-	free(rd->h_mb);
+	page_release(rd);
 	free(rd->h_big);
 	free(rd->h_fmo);
 	free(rd->h_fmo_big);
@@ -266,6 +386,10 @@ static int batch_setup(struct h264_reader *rd, struct rd_batch *b,
 	res = h264_host_engine(&b->eng);
 	if (res < 0)
 		return res;
+	/* (a parse that ended early may have left a page on its way) */
+	res = h264_amd_download_wait(b->eng);
+	if (res < 0)
+		return res;
 	b->n = ns;
 	b->flags = flags;
 	/* macroblock records are only materialised for a caller that looks at
@@ -329,15 +453,34 @@ static int fetch_maps(struct h264_reader *rd, struct h264_amd_engine *eng,
 /* make slice `idx` available in the host images: launch the part of the batch
  * it belongs to unless its records are on the device already, then bring its
  * page over */
+static int batch_fetch_do(struct h264_reader *rd, struct rd_batch *b, size_t idx);
 static int batch_fetch(struct h264_reader *rd, struct rd_batch *b, size_t idx)
 {
-	struct h264_amd_decode_args a;
-	size_t lo, cn, mb_bytes, off;
-	int res;
 	if (idx >= b->lo && idx < b->hi)
 		return 0;
+	if (rd_trace()) {
+		double t = rd_now();
+		int res = batch_fetch_do(rd, b, idx);
+		rd->trace_wait_ms += rd_now() - t;
+		return res;
+	}
+	return batch_fetch_do(rd, b, idx);
+}
+
+static int batch_fetch_do(struct h264_reader *rd, struct rd_batch *b, size_t idx)
+{
+	struct h264_amd_decode_args a;
+	size_t lo, cn;
+	int res;
 	if (idx < b->llo || idx >= b->lhi) {
 		size_t llo = idx - idx % b->launch_n;
+		if (b->phi > b->plo) {
+			/* (the device buffers are about to be overwritten) */
+			res = h264_amd_download_wait(b->eng);
+			if (res < 0)
+				return res;
+			b->plo = b->phi = 0;
+		}
 		size_t ln = b->n - llo < b->launch_n ? b->n - llo : b->launch_n;
 		size_t lmb = b->tier == H264_AMD_TIER_T0 ? ln * b->mb_cap * 4 : 0;
 		res = h264_host_grow(&rd->d_results, &rd->cap_results,
@@ -382,36 +525,44 @@ static int batch_fetch(struct h264_reader *rd, struct rd_batch *b, size_t idx)
 	}
 	lo = idx - idx % b->chunk_n;
 	cn = b->lhi - lo < b->chunk_n ? b->lhi - lo : b->chunk_n;
-	mb_bytes = b->tier == H264_AMD_TIER_T0 ? cn * b->mb_cap * 4 : 0;
-	off = lo - b->llo; /* first slice of the page within the launch */
-
-	res = host_grow((void **)&rd->h_results, &rd->hcap_results,
-			cn * sizeof(*rd->h_results));
-	if (res == 0)
-		res = host_grow((void **)&rd->h_headers, &rd->hcap_headers,
-				cn * sizeof(*rd->h_headers));
-	if (res == 0 && mb_bytes)
-		res = host_grow((void **)&rd->h_mb, &rd->hcap_mb, mb_bytes);
-	if (res < 0)
-		return res;
-	res = h264_amd_download(b->eng, rd->h_results,
-				(const struct h264_amd_slice_result *)rd->d_results + off,
-				cn * sizeof(*rd->h_results));
-	if (res == 0)
-		res = h264_amd_download(b->eng, rd->h_headers,
-					(const struct h264_slice_header *)rd->d_headers + off,
-					cn * sizeof(*rd->h_headers));
-	if (res == 0 && mb_bytes)
-		res = h264_amd_download(b->eng, rd->h_mb,
-					(const uint8_t *)rd->d_mb + off * b->mb_cap * 4,
-					mb_bytes);
-	if (res == 0) {
-		/* maps: only built for streams with slice groups, which launch a
-		 * page at a time (off = 0) */
-		res = fetch_maps(rd, b->eng, cn, &rd->h_fmo, &rd->hcap_fmo);
+	if (b->phi > b->plo) {
+		/* a page is on its way: wait for it, it is the one asked for
+		 * unless the caller jumped */
+		res = h264_amd_download_wait(b->eng);
+		if (res < 0)
+			return res;
+		if (b->plo == lo)
+			rd->cur_page ^= 1;
+		else
+			b->plo = b->phi = 0;
 	}
+	if (b->plo != lo || b->phi == b->plo) {
+		res = page_start(rd, b, &rd->page[rd->cur_page], lo, cn);
+		if (res == 0)
+			res = h264_amd_download_wait(b->eng);
+		if (res < 0)
+			return res;
+	}
+	b->plo = b->phi = 0;
+	rd->h_results = rd->page[rd->cur_page].results;
+	rd->h_headers = rd->page[rd->cur_page].headers;
+	rd->h_mb = rd->page[rd->cur_page].mb;
+	/* maps: only built for streams with slice groups, which launch a page
+	 * at a time (off = 0) */
+	res = fetch_maps(rd, b->eng, cn, &rd->h_fmo, &rd->hcap_fmo);
 	if (res < 0)
 		return res;
+	/* the next page of this launch starts its way to the host now and
+	 * travels while the callbacks of this one are replayed */
+	if (lo + cn < b->lhi) {
+		size_t ncn = b->lhi - (lo + cn) < b->chunk_n ? b->lhi - (lo + cn)
+							     : b->chunk_n;
+		res = page_start(rd, b, &rd->page[rd->cur_page ^ 1], lo + cn, ncn);
+		if (res < 0)
+			return res;
+		b->plo = lo + cn;
+		b->phi = lo + cn + ncn;
+	}
 	b->lo = lo;
 	b->hi = lo + cn;
 	return 0;
@@ -732,13 +883,18 @@ static int run(struct h264_reader *rd, uint32_t flags, const uint8_t *buf,
 	*fatal = 0;
 	plan = malloc((n ? n : 1) * sizeof(*plan));
 	descs = malloc((n ? n : 1) * sizeof(*descs));
+	double t0 = rd_trace() ? rd_now() : 0, t1 = 0, t2 = 0;
 	res = (plan == NULL || descs == NULL) ? -ENOMEM : sync_params(rd);
 	if (res == 0)
 		res = prepass(rd, buf, nals, n, plan, descs, &ns);
+	if (rd_trace())
+		t1 = rd_now();
 	if (res == 0 && ns > 0) {
 		res = batch_setup(rd, &batch, descs, ns, flags);
 		b = &batch;
 	}
+	if (rd_trace())
+		t2 = rd_now();
 	if (res < 0) {
 		*fatal = res;
 		goto out;
@@ -757,6 +913,12 @@ static int run(struct h264_reader *rd, uint32_t flags, const uint8_t *buf,
 	}
 	/* stopped early: the snapshot ran ahead of the context */
 	rd->ps_gen_seen = i == n ? rd->ctx->ps_generation : ~(uint64_t)0;
+	if (rd_trace())
+		fprintf(stderr,
+			"h264_reader: %zu NAL units, %zu slices: pre-pass %.2f ms, "
+			"batch set-up %.2f ms, launch + replay %.2f ms (of which "
+			"waiting for the device %.2f ms)\n",
+			n, ns, t1 - t0, t2 - t1, rd_now() - t2, rd->trace_wait_ms);
 out:
 	free(plan);
 	free(descs);
@@ -783,9 +945,13 @@ int h264_reader_parse(struct h264_reader *rd, uint32_t flags, const uint8_t *buf
 		return res;
 
 	h264_host_lock();
+	double t0 = rd_trace() ? rd_now() : 0, t1 = 0;
+	rd->trace_wait_ms = 0;
 	res = h264_host_grow(&rd->d_buf, &rd->d_buf_cap, len + 64);
 	if (res == 0)
 		res = h264_amd_upload(eng, rd->d_buf, buf, len);
+	if (rd_trace())
+		t1 = rd_now();
 	/* NAL table: sized by a guess, rescanned when the guess was short */
 	cap = rd->cap_nals / sizeof(*nals);
 	if (cap < 4096)
@@ -806,6 +972,9 @@ int h264_reader_parse(struct h264_reader *rd, uint32_t flags, const uint8_t *buf
 				   : h264_amd_download(eng, nals, rd->d_nals,
 						       count * sizeof(*nals));
 	}
+	if (rd_trace())
+		fprintf(stderr, "h264_reader: %zu bytes: upload %.2f ms, scan + NAL "
+				"table %.2f ms\n", len, t1 - t0, rd_now() - t1);
 	if (res == 0) {
 		run(rd, flags, buf, nals, count, 1, off, &fatal);
 		res = fatal;

@@ -287,17 +287,31 @@ __device__ __forceinline__ bool cs_eof(const CbEng &c, const WaveBits &wb)
  * front are also the wait states the v_readlane by `st` needs (its lane select
  * was written by the v_readlane before).  REG: the register operand holding the
  * context, written with the new state */
+#ifdef CS_NM_SALU
+#define CS_NM_A(REG) "s_lshr_b32 %[nm], %[st], 6\n\t" /* (also a wait state) */
+#define CS_NM_B
+#else
+#define CS_NM_A(REG) "v_lshrrev_b32 %[vnm], 6, " REG "\n\t"
+#define CS_NM_B "v_readlane_b32 %[nm], %[vnm], m0\n\t" /* !valMPS */
+#endif
+#ifdef CS_RM_SALU
+#define CS_RM_A
+#define CS_RM_B "s_sub_u32 %[rm], %[R], %[rl]\n\t"
+#else
+#define CS_RM_A "v_sub_u32 %[vrm], %[R], %[vcol]\n\t"
+#define CS_RM_B "v_readlane_b32 %[rm], %[vrm], %[st]\n\t"
+#endif
 #define CS_DEC_TAIL(REG)                                                        \
 	"v_lshrrev_b32 %[vcol], 29, %[R]\n\t" /* 4 + qCodIRangeIdx */            \
 	"v_perm_b32 %[vcol], %[lps4], 0, %[vcol]\n\t"                           \
 	"v_lshlrev_b32 %[vcol], 23, %[vcol]\n\t"                                \
-	"v_sub_u32 %[vrm], %[R], %[vcol]\n\t"                                   \
-	"v_lshrrev_b32 %[vnm], 6, " REG "\n\t"                                  \
+	CS_RM_A                                                                 \
+	CS_NM_A(REG)                                                            \
 	"v_readlane_b32 %[rl], %[vcol], %[st]\n\t"                              \
-	"v_readlane_b32 %[rm], %[vrm], %[st]\n\t"                               \
+	CS_RM_B                                                                 \
 	"v_readlane_b32 %[xa], %[xl], %[st]\n\t"                                \
 	"v_readlane_b32 %[xb], %[xm], %[st]\n\t"                                \
-	"v_readlane_b32 %[nm], %[vnm], m0\n\t" /* !valMPS */                     \
+	CS_NM_B                                                                 \
 	"s_sub_u32 %[t0], %[O], %[rm]\n\t" /* SCC: the MPS path */               \
 	"s_cselect_b32 %[O], %[O], %[t0]\n\t"                                   \
 	"s_cselect_b32 %[R], %[rm], %[rl]\n\t"                                  \
