@@ -9,6 +9,7 @@
 #include <hip/hip_runtime.h>
 #include <cstdio>
 #include <cstdlib>
+#include <cstring>
 #include <cstdint>
 #include <vector>
 #include <algorithm>
@@ -23,7 +24,8 @@
 #define STR(x) STR2(x)
 
 // body: asm text using s10..s19 / v10..v19 as scratch (declared clobbered)
-#define PROBE(name, body)                                                      \
+#define PROBE(name, body) PROBEU(name, body, UNROLL)
+#define PROBEU(name, body, UNR)                                                \
 	__global__ void __launch_bounds__(256) name(uint32_t *out, uint32_t seed) \
 	{                                                                      \
 		__shared__ uint32_t lds[1024];                                 \
@@ -41,7 +43,7 @@
 				"s_mov_b32 s11, s10\n s_mov_b32 s12, s10\n"    \
 				"s_mov_b32 s13, s10\n s_mov_b32 s14, 3\n"      \
 				"s_mov_b32 s15, 0\n"                           \
-				".rept " STR(UNROLL) "\n" body "\n.endr\n"     \
+				".rept " STR(UNR) "\n" body "\n.endr\n"        \
 				"s_waitcnt lgkmcnt(0)\n"                       \
 				"v_add_u32 %0, v10, v11\n v_add_u32 %0, %0, v12\n" \
 				"v_add_u32 %0, %0, v13\n v_add_u32 %0, %0, s10\n"  \
@@ -49,8 +51,9 @@
 				: "+v"(acc)                                    \
 				: "v"(addr)                                    \
 				: "v10", "v11", "v12", "v13", "v14", "v15",    \
-				  "v16", "v17", "s10", "s11", "s12", "s13",    \
-				  "s14", "s15", "s16", "s17", "vcc", "scc",    \
+				  "v16", "v17", "v18", "v19", "s10", "s11",    \
+				  "s12", "s13", "s14", "s15", "s16", "s17",    \
+				  "s18", "s19", "m0", "vcc", "scc",            \
 				  "memory");                                   \
 		}                                                              \
 		if (acc == 0x12345678u)                                        \
@@ -137,7 +140,21 @@ PROBE(k_ilp_2s2v, "s_add_u32 s10, s10, 1\n v_add_u32 v10, v10, 1\n s_add_u32 s11
 // uniform-VGPR level step sketch: shift64, ffbh, add3, sub, lshr, add, lshl_add, cndmask, add, cmp, addc, min
 PROBE(k_level_valu, "v_lshlrev_b64 v[16:17], v15, v[10:11]\n v_ffbh_u32 v12, v17\n v_add3_u32 v13, v12, v14, 1\n v_sub_u32 v16, 32, v13\n v_lshrrev_b32 v16, v16, v17\n v_add_u32 v12, -1, v12\n v_lshl_add_u32 v16, v12, v14, v16\n v_cndmask_b32_e64 v10, v10, v16, s[12:13]\n v_add_u32 v15, v15, v13\n v_cmp_lt_u32 vcc, 2, v12\n v_addc_co_u32 v14, vcc, 0, v14, vcc\n v_min_u32 v14, 6, v14\n v_and_b32 v15, 31, v15\n s_lshl_b64 s[12:13], s[12:13], 1\n s_cmp_lg_u64 s[12:13], 0")
 
-struct T { const char *name; void (*fn)(uint32_t *, uint32_t); int insts; };
+// ---- what bounds a CABAC decision: scalar instructions alone and with the
+// vector-side work of the decision beside them
+PROBEU(k_dec_s12, "s_add_u32 s10, s10, 1\n s_add_u32 s11, s11, 1\n s_add_u32 s10, s10, 1\n s_add_u32 s11, s11, 1\n s_add_u32 s10, s10, 1\n s_add_u32 s11, s11, 1\n s_add_u32 s10, s10, 1\n s_add_u32 s11, s11, 1\n s_add_u32 s10, s10, 1\n s_add_u32 s11, s11, 1\n s_add_u32 s10, s10, 1\n s_add_u32 s11, s11, 1", 8)
+PROBEU(k_dec_s12_rl6, "s_add_u32 s10, s10, 1\n v_readlane_b32 s12, v10, s14\n s_add_u32 s11, s11, 1\n v_readlane_b32 s13, v11, s14\n s_add_u32 s10, s10, 1\n v_readlane_b32 s16, v12, s14\n s_add_u32 s11, s11, 1\n v_readlane_b32 s12, v10, s14\n s_add_u32 s10, s10, 1\n v_readlane_b32 s13, v11, s14\n s_add_u32 s11, s11, 1\n v_readlane_b32 s16, v12, s14\n s_add_u32 s10, s10, 1\n s_add_u32 s11, s11, 1\n s_add_u32 s10, s10, 1\n s_add_u32 s11, s11, 1\n s_add_u32 s10, s10, 1\n s_add_u32 s11, s11, 1", 8)
+PROBEU(k_dec_s12_vp6, "s_add_u32 s10, s10, 1\n v_and_b32 v10, v10, v11\n s_add_u32 s11, s11, 1\n v_and_b32 v12, v12, v13\n s_add_u32 s10, s10, 1\n v_and_b32 v10, v10, v11\n s_add_u32 s11, s11, 1\n v_and_b32 v12, v12, v13\n s_add_u32 s10, s10, 1\n v_and_b32 v10, v10, v11\n s_add_u32 s11, s11, 1\n v_and_b32 v12, v12, v13\n s_add_u32 s10, s10, 1\n s_add_u32 s11, s11, 1\n s_add_u32 s10, s10, 1\n s_add_u32 s11, s11, 1\n s_add_u32 s10, s10, 1\n s_add_u32 s11, s11, 1", 8)
+PROBEU(k_dec_s12_vs6, "s_add_u32 s10, s10, 1\n v_or_b32 v10, s15, v10\n s_add_u32 s11, s11, 1\n v_or_b32 v12, s15, v12\n s_add_u32 s10, s10, 1\n v_or_b32 v10, s15, v10\n s_add_u32 s11, s11, 1\n v_or_b32 v12, s15, v12\n s_add_u32 s10, s10, 1\n v_or_b32 v10, s15, v10\n s_add_u32 s11, s11, 1\n v_or_b32 v12, s15, v12\n s_add_u32 s10, s10, 1\n s_add_u32 s11, s11, 1\n s_add_u32 s10, s10, 1\n s_add_u32 s11, s11, 1\n s_add_u32 s10, s10, 1\n s_add_u32 s11, s11, 1", 8)
+PROBEU(k_dec_s9, "s_add_u32 s10, s10, 1\n s_add_u32 s11, s11, 1\n s_add_u32 s10, s10, 1\n s_add_u32 s11, s11, 1\n s_add_u32 s10, s10, 1\n s_add_u32 s11, s11, 1\n s_add_u32 s10, s10, 1\n s_add_u32 s11, s11, 1\n s_add_u32 s10, s10, 1", 8)
+PROBEU(k_dec_full, "v_readlane_b32 s12, v10, s14\n v_lshrrev_b32 v16, 29, s10\n v_perm_b32 v16, v11, 0, v16\n v_lshlrev_b32 v16, 23, v16\n v_sub_u32 v17, s10, v16\n v_lshrrev_b32 v13, 6, v10\n v_readlane_b32 s13, v16, s14\n v_readlane_b32 s16, v17, s14\n v_readlane_b32 s17, v11, s14\n v_readlane_b32 s12, v12, s14\n v_readlane_b32 s13, v13, s14\n s_sub_u32 s11, s11, s16\n s_cselect_b32 s11, s11, s16\n s_cselect_b32 s10, s16, s13\n s_cselect_b32 s17, s17, s12\n s_addc_u32 s12, s13, 0\n s_xor_b32 s17, s17, s12\n s_mov_b32 m0, s14\n v_writelane_b32 v10, s17, m0\n s_flbit_i32_b32 s16, s10\n s_lshl_b32 s10, s10, s16\n s_lshl_b32 s11, s11, s16", 8)
+
+PROBEU(k_dec_valu, "s_mov_b32 m0, s14\n v_readlane_b32 s10, v10, m0\n v_lshrrev_b32 v16, 29, v15\n v_perm_b32 v16, v11, 0, v16\n v_lshlrev_b32 v16, 23, v16\n v_sub_u32 v17, v15, v16\n v_readlane_b32 s11, v17, s10\n v_cmp_gt_u32_e64 s[16:17], s11, v14\n v_subrev_u32 v18, s11, v14\n v_cndmask_b32_e64 v14, v18, v14, s[16:17]\n v_cndmask_b32_e64 v19, v16, v17, s[16:17]\n v_cndmask_b32_e64 v18, v12, v13, s[16:17]\n v_readlane_b32 s12, v19, s10\n v_readlane_b32 s13, v18, s10\n s_xor_b32 s13, s13, s10\n v_writelane_b32 v10, s13, m0\n v_ffbh_u32 v19, s12\n v_lshlrev_b32 v15, v19, s12\n v_lshlrev_b32 v14, v19, v14\n s_bfe_i64 s[18:19], s[10:11], 0x10006\n s_xor_b64 vcc, s[16:17], s[18:19]\n v_and_b32 v18, 0x1ffff, v14\n v_cmp_eq_u32 vcc, 0, v18", 8)
+
+PROBEU(k_dec_v5, "v_readlane_b32 s12, v10, s14\n v_lshrrev_b32 v16, 29, s10\n v_perm_b32 v16, v11, 0, v16\n v_lshlrev_b32 v16, 23, v16\n v_sub_u32 v17, s10, v16\n v_lshrrev_b32 v13, 6, v10\n v_readlane_b32 s13, v16, s14\n v_readlane_b32 s16, v17, s14\n v_readlane_b32 s13, v13, s14\n s_sub_u32 s11, s11, s16\n s_cselect_b32 s11, s11, s16\n s_cselect_b32 s10, s16, s13\n s_cselect_b64 s[18:19], -1, 0\n v_cndmask_b32_e64 v18, v11, v12, s[18:19]\n s_addc_u32 s12, s13, 0\n v_readlane_b32 s17, v18, s14\n s_xor_b32 s17, s17, s12\n s_mov_b32 m0, s14\n v_writelane_b32 v10, s17, m0\n s_flbit_i32_b32 s16, s10\n s_lshl_b32 s10, s10, s16\n s_lshl_b32 s11, s11, s16", 8)
+PROBEU(k_dec_v2, "s_mov_b32 m0, s14\n v_readlane_b32 s12, v10, m0\n s_bfe_u32 s16, s10, 0x3001d\n v_perm_b32 v16, v11, 0, s16\n v_lshlrev_b32 v16, 23, v16\n s_lshr_b32 s17, s12, 6\n s_nop 0\n v_readlane_b32 s13, v16, s14\n v_readlane_b32 s16, v11, s14\n v_readlane_b32 s18, v12, s14\n s_sub_u32 s19, s10, s13\n s_sub_u32 s15, s11, s19\n s_cselect_b32 s11, s11, s15\n s_cselect_b32 s10, s19, s13\n s_cselect_b32 s16, s18, s16\n s_addc_u32 s17, s17, 0\n s_xor_b32 s16, s16, s12\n v_writelane_b32 v10, s16, m0\n s_flbit_i32_b32 s15, s10\n s_lshl_b32 s10, s10, s15\n s_lshl_b32 s11, s11, s15", 8)
+
+struct T { const char *name; void (*fn)(uint32_t *, uint32_t); int insts; int unroll = UNROLL; };
 
 int main(int argc, char **argv)
 {
@@ -182,11 +199,20 @@ int main(int argc, char **argv)
 		{"s_bfe", k_s_bfe, 1}, {"s_ff1_b64", k_s_ff1_64, 1}, {"s_cmp+cselect", k_s_cselect, 2},
 		{"s_bitset0_b64", k_s_bitset0, 1}, {"m0+s_movrels", k_s_movrels, 2},
 		{"ilp_2s2v", k_ilp_2s2v, 4}, {"level_valu(13v+2s)", k_level_valu, 15},
+		{"12 salu", k_dec_s12, 12, 8}, {"12 salu + 6 readlane", k_dec_s12_rl6, 18, 8},
+		{"12 salu + 6 valu vgpr", k_dec_s12_vp6, 18, 8},
+		{"12 salu + 6 valu sgpr", k_dec_s12_vs6, 18, 8}, {"9 salu", k_dec_s9, 9, 8},
+		{"decision (10s+12v)", k_dec_full, 22, 8},
+		{"decision on the vector side", k_dec_valu, 23, 8},
+		{"decision, state change picked in the lanes", k_dec_v5, 22, 8},
+		{"decision, 13 scalar + 4 readlane", k_dec_v2, 21, 8},
 	};
 	const double ghz = 2.4;
 	printf("%-22s %5s | cycles per pattern per SIMD at w waves/SIMD (cycles per pattern per wave)\n",
 	       "pattern", "insts");
 	for (auto &t : tests) {
+		if (argc > 1 && strstr(t.name, argv[1]) == NULL)
+			continue;
 		printf("%-22s %5d |", t.name, t.insts);
 		for (int w : {1, 2, 4}) {
 			int blocks = 256 * w; // 256-thread blocks: one wave per SIMD each
@@ -204,7 +230,7 @@ int main(int argc, char **argv)
 			}
 			std::sort(ms.begin(), ms.end());
 			double cyc = ms[1] * 1e-3 * ghz * 1e9; // per wave wall cycles
-			double per_wave = cyc / ((double)ITER * UNROLL);
+			double per_wave = cyc / ((double)ITER * t.unroll);
 			printf("  w=%d %6.2f (%6.2f)", w, per_wave / w, per_wave);
 		}
 		printf("\n");
