@@ -301,6 +301,21 @@ __device__ __forceinline__ bool cs_eof(const CbEng &c, const WaveBits &wb)
 #define CS_RM_A "v_sub_u32 %[vrm], %[R], %[vcol]\n\t"
 #define CS_RM_B "v_readlane_b32 %[rm], %[vrm], %[st]\n\t"
 #endif
+/* the state change of the path taken: both tables read and one picked on the
+ * scalar side (CS_X_SCALAR), or picked in all lanes under a mask made from
+ * SCC and read once */
+#ifdef CS_X_SCALAR
+#define CS_X_SEL                                                               \
+	"v_readlane_b32 %[xa], %[xl], %[st]\n\t"                                \
+	"v_readlane_b32 %[xb], %[xm], %[st]\n\t"                                \
+	"s_cselect_b32 %[xa], %[xb], %[xa]\n\t"
+#define CS_X_GET
+#else
+#define CS_X_SEL                                                               \
+	"s_cselect_b64 %[m64], -1, 0\n\t"                                       \
+	"v_cndmask_b32_e64 %[vnm], %[xl], %[xm], %[m64]\n\t"
+#define CS_X_GET "v_readlane_b32 %[xa], %[vnm], %[st]\n\t"
+#endif
 #define CS_DEC_TAIL(REG)                                                        \
 	"v_lshrrev_b32 %[vcol], 29, %[R]\n\t" /* 4 + qCodIRangeIdx */            \
 	"v_perm_b32 %[vcol], %[lps4], 0, %[vcol]\n\t"                           \
@@ -309,14 +324,13 @@ __device__ __forceinline__ bool cs_eof(const CbEng &c, const WaveBits &wb)
 	CS_NM_A(REG)                                                            \
 	"v_readlane_b32 %[rl], %[vcol], %[st]\n\t"                              \
 	CS_RM_B                                                                 \
-	"v_readlane_b32 %[xa], %[xl], %[st]\n\t"                                \
-	"v_readlane_b32 %[xb], %[xm], %[st]\n\t"                                \
 	CS_NM_B                                                                 \
 	"s_sub_u32 %[t0], %[O], %[rm]\n\t" /* SCC: the MPS path */               \
+	CS_X_SEL                                                                \
 	"s_cselect_b32 %[O], %[O], %[t0]\n\t"                                   \
 	"s_cselect_b32 %[R], %[rm], %[rl]\n\t"                                  \
-	"s_cselect_b32 %[xa], %[xb], %[xa]\n\t"                                 \
 	"s_addc_u32 %[bin], %[nm], 0\n\t" /* bit 0: the bin */                   \
+	CS_X_GET                                                                \
 	"s_xor_b32 %[xa], %[xa], %[st]\n\t"                                     \
 	"v_writelane_b32 " REG ", %[xa], m0\n\t"                                \
 	"s_flbit_i32_b32 %[t0], %[R]\n\t"                                       \
@@ -355,6 +369,7 @@ __device__ __forceinline__ uint32_t cs_dec(CbEng &c, WaveBits &wb, uint32_t &reg
 {
 	cs_refill(c, wb);
 	uint32_t st, rl, xa, xb, rm, t0, nm, bin, vcol, vrm, vnm;
+	uint64_t m64;
 	/* (the engine state is kept on the scalar side by cs_pin() behind every
 	 * other operation on it) */
 	slot = (uint32_t)__builtin_amdgcn_readfirstlane((int)slot);
@@ -366,7 +381,7 @@ __device__ __forceinline__ uint32_t cs_dec(CbEng &c, WaveBits &wb, uint32_t &reg
 		     "v_readlane_b32 %[st], %[reg], m0\n\t"
 		     CS_DEC_BODY
 		     : [O] "+s"(c.O), [R] "+s"(c.R), [reg] "+v"(reg), [st] "=&s"(st),
-		       [rl] "=&s"(rl), [xa] "=&s"(xa), [xb] "=&s"(xb), [rm] "=&s"(rm),
+		       [rl] "=&s"(rl), [xa] "=&s"(xa), [xb] "=&s"(xb), [m64] "=&s"(m64), [rm] "=&s"(rm),
 		       [t0] "=&s"(t0), [nm] "=&s"(nm), [bin] "=&s"(bin),
 		       [vcol] "=&v"(vcol), [vrm] "=&v"(vrm), [vnm] "=&v"(vnm)
 		     : [slot] "s"(slot), [lps4] "v"(c.lps4), [xl] "v"(c.xl),
@@ -665,6 +680,7 @@ __device__ __forceinline__ uint32_t cs_run(CbEng &c, WaveBits &wb, uint32_t &reg
 					   uint32_t lane0, uint32_t cap, uint32_t maxn)
 {
 	uint32_t st, rl, xa, xb, rm, t0, nm, bin, vcol, vrm, vnm, again;
+	uint64_t m64;
 	uint32_t cnt = 0;
 	lane0 = (uint32_t)__builtin_amdgcn_readfirstlane((int)lane0);
 	cap = (uint32_t)__builtin_amdgcn_readfirstlane((int)cap);
@@ -694,7 +710,7 @@ __device__ __forceinline__ uint32_t cs_run(CbEng &c, WaveBits &wb, uint32_t &reg
 			     : [O] "+s"(c.O), [R] "+s"(c.R), [reg] "+v"(reg),
 			       [lane] "+s"(lane0), [cnt] "+s"(cnt), [st] "=&s"(st),
 			       [rl] "=&s"(rl), [xa] "=&s"(xa), [xb] "=&s"(xb),
-			       [rm] "=&s"(rm), [t0] "=&s"(t0), [nm] "=&s"(nm),
+			       [m64] "=&s"(m64), [rm] "=&s"(rm), [t0] "=&s"(t0), [nm] "=&s"(nm),
 			       [bin] "=&s"(bin), [vcol] "=&v"(vcol), [vrm] "=&v"(vrm), [vnm] "=&v"(vnm),
 			       [again] "=&s"(again)
 			     : [cap] "s"(cap), [maxn] "s"(maxn), [lps4] "v"(c.lps4),
@@ -723,6 +739,7 @@ __device__ __forceinline__ uint32_t cs_sigmap_run(CbEng &c, uint32_t &sreg,
 						  uint64_t &sig)
 {
 	uint32_t st, rl, xa, xb, rm, t0, nm, bin, vcol, vrm, vnm, reason;
+	uint64_t m64;
 	cs_pin(c);
 	lane_io = (uint32_t)__builtin_amdgcn_readfirstlane((int)lane_io);
 	end_lane = (uint32_t)__builtin_amdgcn_readfirstlane((int)end_lane);
@@ -764,7 +781,7 @@ __device__ __forceinline__ uint32_t cs_sigmap_run(CbEng &c, uint32_t &sreg,
 		     : [O] "+s"(c.O), [R] "+s"(c.R), [sreg] "+v"(sreg),
 		       [lreg] "+v"(lreg), [lane] "+s"(lane_io), [sig] "+s"(sig),
 		       [st] "=&s"(st), [rl] "=&s"(rl), [xa] "=&s"(xa), [xb] "=&s"(xb),
-		       [rm] "=&s"(rm), [t0] "=&s"(t0), [nm] "=&s"(nm),
+		       [m64] "=&s"(m64), [rm] "=&s"(rm), [t0] "=&s"(t0), [nm] "=&s"(nm),
 		       [bin] "=&s"(bin), [vcol] "=&v"(vcol), [vrm] "=&v"(vrm), [vnm] "=&v"(vnm), [reason] "=&s"(reason)
 		     : [end] "s"(end_lane), [phase] "s"(phase), [lps4] "v"(c.lps4),
 		       [xl] "v"(c.xl), [xm] "v"(c.xm)
@@ -1036,6 +1053,8 @@ cs_slice_data(CbEng &c, WaveBits &wb, CbCtx &x, uint8_t *stage, uint8_t *row,
 			const bool is_intra = it != 0xffu;
 			bool i16 = false;
 			bool ok = true;
+			bool nz_bytes = false;
+			uint32_t nz_val = 0;
 
 			if (it == 25u) {
 				/* ---- I_PCM: the terminating bin ended the arithmetic
@@ -1647,22 +1666,18 @@ cs_slice_data(CbEng &c, WaveBits &wb, CbCtx &x, uint8_t *stage, uint8_t *row,
 				    : lane == 16 ? refw0
 				    : lane == 17 ? refw1
 						 : H;
-				/* nz_coeff: four counts per dword */
-				{
-					const uint32_t q = 4u * (lane & 15u);
-					uint32_t n0 = (uint32_t)__shfl((int)NZ, (int)q);
-					uint32_t n1 = (uint32_t)__shfl((int)NZ, (int)(q + 1u));
-					uint32_t n2 = (uint32_t)__shfl((int)NZ, (int)(q + 2u));
-					uint32_t n3 = (uint32_t)__shfl((int)NZ, (int)(q + 3u));
-					uint32_t w = n0 | (n1 << 8) | (n2 << 16) | (n3 << 24);
-					uint32_t wl = (uint32_t)__shfl((int)w, (int)(lane - 4u));
-					H = lane >= 4u && lane < 16u ? wl : H;
-				}
+				nz_bytes = true;
+				nz_val = NZ;
 			}
 			if (cs_eof(c, wb))
 				return -EIO;
 			CS_T(16);
 			*reinterpret_cast<uint32_t *>(stage + 4u * lane) = H;
+			/* nz_coeff[48]: lane b holds the count of block b -- a byte
+			 * each, behind the head's dwords (one LDS instruction
+			 * instead of five cross-lane gathers to pack them) */
+			if (nz_bytes && lane < 48u)
+				stage[16u + lane] = (uint8_t)nz_val;
 			sd_emit_staged(o, stage, mbidx, lane);
 			CS_T(17);
 		}
