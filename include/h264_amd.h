@@ -142,6 +142,13 @@ static inline uint32_t h264_amd_t2_stride(uint32_t chroma_array_type)
  * pictures of width 0, end with H264_AMD_E_UNSUPPORTED in product and oracle
  * alike; their headers are still parsed.  Bounds the per-wave row context. */
 #define H264_AMD_MAX_PIC_WIDTH_MBS 1056u
+/* The same for CABAC slice data (H264_AMD_READER_FLAGS_CABAC): 14 080 pixels.
+ * A macroblock column keeps 40 bytes of row context there (coded_block_flag,
+ * |mvd|, ref_idx of its bottom row) against 16 for CAVLC, and four slices'
+ * rows share one compute unit's LDS.  Wider pictures (level 6.2 would allow
+ * 1055 macroblocks; 8K is 512): H264_AMD_E_UNSUPPORTED behind the header, in
+ * product and oracle alike, not a failed launch. */
+#define H264_AMD_MAX_CABAC_WIDTH_MBS 880u
 
 /* Slice groups (FMO): the macroblock-to-slice-group map of a slice is built
  * for pictures of up to H264_AMD_FMO_MAX_PIC_MBS macroblocks (what level 6.2
@@ -154,6 +161,13 @@ static inline uint32_t h264_amd_t2_stride(uint32_t chroma_array_type)
  * for run_length_minus1 = 2^32 - 2 and its loop need not end). */
 #define H264_AMD_FMO_MAX_PIC_MBS 139264u
 #define H264_AMD_FMO_MAX_BOX_OUT_UNITS 32768u
+/* The box-out walk (8.2.2.4) steps over units it has filled already once the
+ * picture's edge clips the box; in a picture of extreme aspect ratio nearly
+ * all steps are of that kind (1056 x 6 macroblocks: 177 steps per unit, n^2 at
+ * worst).  The walk ends after this many steps, units not reached stay in
+ * slice group 1 -- enough for every aspect ratio up to 14 : 1; product and
+ * oracle alike (found by the hostile-parameter fuzz, round 3). */
+#define H264_AMD_FMO_BOX_OUT_STEPS(n) (8ull * (n) + 64ull)
 
 /* Per-slice outcome, 64 bytes.  status mirrors what _h264_read_nalu would
  * have returned for this NAL (0, -EIO, -EINVAL ...). */

@@ -906,7 +906,9 @@ extern "C" int h264_amd_decode_slices(struct h264_amd_engine *e,
 		c.results = a.results;
 		c.headers = a.headers;
 		c.mb_out = a.mb_out;
-		c.row_pitch = a.row_pitch;
+		c.row_pitch = a.row_pitch < H264_AMD_MAX_CABAC_WIDTH_MBS
+				      ? a.row_pitch
+				      : H264_AMD_MAX_CABAC_WIDTH_MBS;
 		c.order = a.order;
 		c.wave_lds_bytes =
 			(CS_ROW_OFF + CS_ROW_STRIDE * c.row_pitch + 255u) & ~255u;

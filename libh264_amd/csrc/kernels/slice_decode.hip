@@ -584,9 +584,11 @@ __device__ __forceinline__ int sd_fmo_build(const dev_fmo *f, const SliceState &
 		int32_t y = (int32_t)((H - (uint32_t)dir) / 2u);
 		int32_t left = x, top = y, right = x, bottom = y;
 		int32_t xd = dir - 1, yd = dir;
-		/* every vacant step fills a unit; steps over filled units are
-		 * bounded by the walk around the growing box */
-		uint32_t k = 0, guard = 8u * n + 64u;
+		/* every vacant step fills a unit; steps over filled units come
+		 * with a box that the picture's edge clips, and are bounded
+		 * (H264_AMD_FMO_BOX_OUT_STEPS, h264_amd.h: the oracle stops at the
+		 * same step) */
+		uint32_t k = 0, guard = (uint32_t)H264_AMD_FMO_BOX_OUT_STEPS(n);
 		while (k < units0 && guard-- > 0) {
 			uint32_t cell = (uint32_t)y * W + (uint32_t)x;
 			uint32_t word = wb_uniform(bits[cell >> 5]);

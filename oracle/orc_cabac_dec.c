@@ -1095,7 +1095,7 @@ int orc_cabac_slice_data(struct h264_bitstream *bs, struct orc_reader *rd)
 	if (ctx->derived.MbaffFrameFlag || ctx->pps->num_slice_groups_minus1 > 0)
 		return H264_AMD_E_UNSUPPORTED;
 	if (ctx->sps_derived.PicWidthInMbs == 0 ||
-	    ctx->sps_derived.PicWidthInMbs > H264_AMD_MAX_PIC_WIDTH_MBS)
+	    ctx->sps_derived.PicWidthInMbs > H264_AMD_MAX_CABAC_WIDTH_MBS)
 		return H264_AMD_E_UNSUPPORTED;
 	tables_init();
 	if (rd->cbs.slice_data_begin)
