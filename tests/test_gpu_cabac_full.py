@@ -138,3 +138,27 @@ def test_damaged_444_field(engine):
             nal[p] ^= 1 << rnd.randrange(8)
         nals.append(bytes(nal))
     compare(engine, head, nals)
+
+
+def test_picture_wider_than_the_row_context(engine):
+    """H264_AMD_MAX_CABAC_WIDTH_MBS: CABAC slice data of a wider picture ends
+    with H264_AMD_E_UNSUPPORTED behind the header, in kernel and oracle, and
+    does not take the launch with it (tools/fuzz_params.py found the launch
+    failing with -E2BIG); at the limit it decodes."""
+    for width, want in ((881, -38), (880, 0)):
+        cfg = cabac_cfg(width_mbs=width, height_mbs=1)
+        wide = cabac_slice(cfg, 7, 2, 0, width)
+        head = [gen.sps(cfg), gen.pps(cfg)]
+        ref, res = compare(engine, head, [gen.slice_nal(cfg, wide)],
+                           tier=TIER_T0)
+        assert res[0].status == want and (res[0].flags & 1), width
+    # a batch that holds both: the narrow picture's slices are not affected
+    small = cabac_cfg()
+    big = cabac_cfg(width_mbs=900, height_mbs=1)
+    big.sps_id, big.pps_id = 3, 5
+    nals = [gen.slice_nal(small, cabac_slice(small, 11, 2)),
+            gen.slice_nal(big, cabac_slice(big, 12, 2, 0, 900)),
+            gen.slice_nal(small, cabac_slice(small, 13, 0))]
+    head = [gen.sps(small), gen.pps(small), gen.sps(big), gen.pps(big)]
+    ref, res = compare(engine, head, nals, tier=TIER_T2)
+    assert [r.status for r in res] == [0, -38, 0]

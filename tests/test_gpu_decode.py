@@ -565,3 +565,29 @@ def test_slice_group_limits(engine):
     cfg, _ = fmo_cfg(0)
     cfg.run_length_minus1[1] = 0xfffffffe
     assert run(cfg)[0].status == 0
+
+
+def test_box_out_of_an_extreme_aspect_ratio(engine):
+    """1056 x 6 macroblocks: once the picture's edge clips the box, a lap of the
+    box-out walk costs two thousand steps and fills a dozen units; kernel and
+    oracle stop after H264_AMD_FMO_BOX_OUT_STEPS steps and agree on the map
+    that leaves (found by tools/fuzz_dropin.py params, seed 61733: the oracle
+    had no bound).  The addresses of the slice's macroblocks come out of the
+    map: compared through the drop-in's callbacks in test_gpu_dropin.py; here
+    the records and the map's effect on the neighbour availability."""
+    from test_oracle_vs_generator import fmo_cfg
+    cfg, _ = fmo_cfg(3)
+    cfg.width_mbs, cfg.height_mbs = 1056, 6
+    cfg.slice_group_change_rate_minus1 = 0
+    for cycle, first in ((900, 0), (2500, 0), (6336, 0), (900, 2000)):
+        s = streams.rich_slice(cfg, 2300 + cycle, 2, first, 400,
+                               slice_group_change_cycle=cycle, hdr_extras=0)
+        nals = [gen.sps(cfg), gen.pps(cfg), gen.slice_nal(cfg, s)]
+        ref = orc.parse_nalus(nals, flags=1)
+        params = make_params(ref)
+        buf, offs, sizes = streams.pack_nals(nals[2:])
+        out = engine.decode_slices(
+            params, engine.upload(buf), [(offs[0], sizes[0], params.epoch)],
+            reader_flags=1, tier=TIER_T2, mb_capacity=402, want_headers=True)
+        res = engine.fetch_results(out)
+        assert result_fields(res[0]) == result_fields(ref.results[0]), cycle

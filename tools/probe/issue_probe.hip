@@ -154,6 +154,25 @@ PROBEU(k_dec_valu, "s_mov_b32 m0, s14\n v_readlane_b32 s10, v10, m0\n v_lshrrev_
 PROBEU(k_dec_v5, "v_readlane_b32 s12, v10, s14\n v_lshrrev_b32 v16, 29, s10\n v_perm_b32 v16, v11, 0, v16\n v_lshlrev_b32 v16, 23, v16\n v_sub_u32 v17, s10, v16\n v_lshrrev_b32 v13, 6, v10\n v_readlane_b32 s13, v16, s14\n v_readlane_b32 s16, v17, s14\n v_readlane_b32 s13, v13, s14\n s_sub_u32 s11, s11, s16\n s_cselect_b32 s11, s11, s16\n s_cselect_b32 s10, s16, s13\n s_cselect_b64 s[18:19], -1, 0\n v_cndmask_b32_e64 v18, v11, v12, s[18:19]\n s_addc_u32 s12, s13, 0\n v_readlane_b32 s17, v18, s14\n s_xor_b32 s17, s17, s12\n s_mov_b32 m0, s14\n v_writelane_b32 v10, s17, m0\n s_flbit_i32_b32 s16, s10\n s_lshl_b32 s10, s10, s16\n s_lshl_b32 s11, s11, s16", 8)
 PROBEU(k_dec_v2, "s_mov_b32 m0, s14\n v_readlane_b32 s12, v10, m0\n s_bfe_u32 s16, s10, 0x3001d\n v_perm_b32 v16, v11, 0, s16\n v_lshlrev_b32 v16, 23, v16\n s_lshr_b32 s17, s12, 6\n s_nop 0\n v_readlane_b32 s13, v16, s14\n v_readlane_b32 s16, v11, s14\n v_readlane_b32 s18, v12, s14\n s_sub_u32 s19, s10, s13\n s_sub_u32 s15, s11, s19\n s_cselect_b32 s11, s11, s15\n s_cselect_b32 s10, s19, s13\n s_cselect_b32 s16, s18, s16\n s_addc_u32 s17, s17, 0\n s_xor_b32 s16, s16, s12\n v_writelane_b32 v10, s16, m0\n s_flbit_i32_b32 s15, s10\n s_lshl_b32 s10, s10, s15\n s_lshl_b32 s11, s11, s15", 8)
 
+// ---- constants against registers as operands of the same operation
+PROBE(k_c_lshl_v, "v_lshlrev_b32 v10, v15, v10")
+PROBE(k_c_lshr_c, "v_lshrrev_b32 v10, 3, v10")
+PROBE(k_c_add_v, "v_add_u32 v10, v10, v11")
+PROBE(k_c_and_c, "v_and_b32 v10, 15, v10")
+PROBE(k_c_and_lit, "v_and_b32 v10, 0x1234, v10")
+PROBE(k_c_or_v, "v_or_b32 v10, v10, v11")
+PROBE(k_c_xor_v, "v_xor_b32 v10, v10, v11")
+PROBE(k_c_xor_c, "v_xor_b32 v10, 1, v10")
+PROBE(k_c_sub_c, "v_subrev_u32 v10, 1, v10")
+PROBE(k_c_cmp_c_cnd, "v_cmp_eq_u32 vcc, 5, v10\n v_cndmask_b32 v12, v12, v13, vcc")
+PROBE(k_c_max_v, "v_max_u32 v10, v10, v11")
+PROBE(k_c_lshl_or, "v_lshl_or_b32 v10, v10, v15, v11")
+PROBE(k_c_and_or, "v_and_or_b32 v10, v10, v11, v12")
+PROBE(k_c_mbcnt, "v_mbcnt_lo_u32_b32 v10, v11, v10")
+PROBE(k_c_ashr, "v_ashrrev_i32 v10, v15, v10")
+PROBE(k_c_perm, "v_perm_b32 v10, v10, v11, v12")
+PROBE(k_c_cndmask_after_scmp, "s_cmp_eq_u32 s10, 0\n s_cselect_b64 s[16:17], -1, 0\n v_cndmask_b32_e64 v10, v10, v11, s[16:17]")
+
 struct T { const char *name; void (*fn)(uint32_t *, uint32_t); int insts; int unroll = UNROLL; };
 
 int main(int argc, char **argv)
@@ -199,6 +218,16 @@ int main(int argc, char **argv)
 		{"s_bfe", k_s_bfe, 1}, {"s_ff1_b64", k_s_ff1_64, 1}, {"s_cmp+cselect", k_s_cselect, 2},
 		{"s_bitset0_b64", k_s_bitset0, 1}, {"m0+s_movrels", k_s_movrels, 2},
 		{"ilp_2s2v", k_ilp_2s2v, 4}, {"level_valu(13v+2s)", k_level_valu, 15},
+		{"opnd v_lshl vgpr", k_c_lshl_v, 1}, {"opnd v_lshr const", k_c_lshr_c, 1},
+		{"opnd v_add vgpr", k_c_add_v, 1}, {"opnd v_and const", k_c_and_c, 1},
+		{"opnd v_and literal", k_c_and_lit, 1}, {"opnd v_or vgpr", k_c_or_v, 1},
+		{"opnd v_xor vgpr", k_c_xor_v, 1}, {"opnd v_xor const", k_c_xor_c, 1},
+		{"opnd v_subrev const", k_c_sub_c, 1},
+		{"opnd v_cmp const + cndmask", k_c_cmp_c_cnd, 2},
+		{"opnd v_max vgpr", k_c_max_v, 1}, {"opnd v_lshl_or", k_c_lshl_or, 1},
+		{"opnd v_and_or", k_c_and_or, 1}, {"opnd v_mbcnt", k_c_mbcnt, 1},
+		{"opnd v_ashr vgpr", k_c_ashr, 1}, {"opnd v_perm vgpr", k_c_perm, 1},
+		{"opnd s_cmp+cselect64+cndmask", k_c_cndmask_after_scmp, 3},
 		{"12 salu", k_dec_s12, 12, 8}, {"12 salu + 6 readlane", k_dec_s12_rl6, 18, 8},
 		{"12 salu + 6 valu vgpr", k_dec_s12_vp6, 18, 8},
 		{"12 salu + 6 valu sgpr", k_dec_s12_vs6, 18, 8}, {"9 salu", k_dec_s9, 9, 8},
