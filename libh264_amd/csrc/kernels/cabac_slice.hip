@@ -532,7 +532,7 @@ __device__ __forceinline__ void cs_rot3(uint32_t (&r)[3])
 #define CS_ROLE_BOT 4u /* bottom row of the current macroblock */
 #define CS_ROLE_IN 8u /* a block of the current macroblock */
 
-struct CbLanes {
+struct CbLanesWide {
 	/* coded_block_flag grid, register 0: luma 5x5 at lanes 0..24; without
 	 * 4:4:4 the chroma AC grids (3 wide) at 25.. (Cb) and 40.. (Cr) */
 	uint32_t g_role, g_off, g_src;
@@ -543,7 +543,8 @@ struct CbLanes {
 	uint32_t l_kind; /* 0 mvd x, 1 mvd y, 2 ref_idx, 3 nothing */
 };
 
-__device__ __forceinline__ void cs_lane_roles(CbLanes &L, uint32_t lane, uint32_t cat)
+__device__ __forceinline__ void cs_lane_roles_wide(CbLanesWide &L, uint32_t lane,
+						   uint32_t cat)
 {
 	L.g_role = 0;
 	L.g_off = 0;
@@ -612,6 +613,34 @@ __device__ __forceinline__ void cs_lane_roles(CbLanes &L, uint32_t lane, uint32_
 		}
 	}
 }
+
+/* the same, packed: nine per-lane constants in two registers (they are looked
+ * at a few times per macroblock; kept apart they cost the kernel six registers
+ * it does not have, spilled and reloaded around every residual).
+ * gw: g_role | g_off << 4 | g_src << 10 | l_kind << 16 | (l_x + 1) << 18 |
+ *     (l_y + 1) << 21;   lw: l_role | l_off << 4 | l_src << 10 */
+struct CbLanes {
+	uint32_t gw, lw;
+};
+
+__device__ __forceinline__ void cs_lane_roles(CbLanes &P, uint32_t lane, uint32_t cat)
+{
+	CbLanesWide L;
+	cs_lane_roles_wide(L, lane, cat);
+	P.gw = L.g_role | (L.g_off << 4) | (L.g_src << 10) | (L.l_kind << 16) |
+	       ((uint32_t)(L.l_x + 1) << 18) | ((uint32_t)(L.l_y + 1) << 21);
+	P.lw = L.l_role | (L.l_off << 4) | (L.l_src << 10);
+}
+
+#define CL_G_ROLE(P) ((P).gw & 15u)
+#define CL_G_OFF(P) (((P).gw >> 4) & 63u)
+#define CL_G_SRC(P) (((P).gw >> 10) & 63u)
+#define CL_L_KIND(P) (((P).gw >> 16) & 3u)
+#define CL_L_X(P) ((int32_t)(((P).gw >> 18) & 7u) - 1)
+#define CL_L_Y(P) ((int32_t)(((P).gw >> 21) & 7u) - 1)
+#define CL_L_ROLE(P) ((P).lw & 15u)
+#define CL_L_OFF(P) (((P).lw >> 4) & 63u)
+#define CL_L_SRC(P) (((P).lw >> 10) & 63u)
 
 /* lane of a grid cell; x, y may be -1 */
 __device__ __forceinline__ uint32_t cs_g5(uint32_t x, uint32_t y)
@@ -930,6 +959,7 @@ cs_slice_data(CbEng &c, WaveBits &wb, CbCtx &x, uint8_t *stage, uint8_t *row,
 				break;
 			}
 		}
+		asm volatile("" : "+v"(LN.gw), "+v"(LN.lw));
 		/* neighbours inside the slice (6.4.9; ref src/h264_macroblock.c:306-351
 		 * for the same rule) */
 		uint8_t *rowent = row + CS_ROW_STRIDE * mbx;
@@ -1161,14 +1191,14 @@ cs_slice_data(CbEng &c, WaveBits &wb, CbCtx &x, uint8_t *stage, uint8_t *row,
 				}
 
 				bool no_sub8 = true;
-				uint32_t pred_lo = 0, pred_hi = 0, refw0 = 0, refw1 = 0;
+				uint32_t pred_lo = 0, pred_hi = 0;
 				if (!is_intra) {
 					/* grids of |mvd| and ref_idx */
 #pragma unroll
 					for (uint32_t l = 0; l < 2; l++)
 						LL[l] = cs_grid_open(
-							LL[l], LN.l_role, LN.l_off + 12u * l,
-							LN.l_src, rowent, vA != 0, vB != 0, 0);
+							LL[l], CL_L_ROLE(LN), CL_L_OFF(LN) + 12u * l,
+							CL_L_SRC(LN), rowent, vA != 0, vB != 0, 0);
 				} else {
 					LL[0] = LL[1] = 0;
 				}
@@ -1251,6 +1281,10 @@ cs_slice_data(CbEng &c, WaveBits &wb, CbCtx &x, uint8_t *stage, uint8_t *row,
 							pred_hi |= nib << (4u * (b - 8u));
 					}
 				}
+				/* (into the record's head at once: two registers less
+				 * to carry over the residual) */
+				H = cs_wl(H, pred_lo, 2);
+				H = cs_wl(H, pred_hi, 3);
 				if (is_intra && c12) {
 					/* intra_chroma_pred_mode */
 					icp = cs_dec(c, wb, x.mb1,
@@ -1301,15 +1335,12 @@ cs_slice_data(CbEng &c, WaveBits &wb, CbCtx &x, uint8_t *stage, uint8_t *row,
 							}
 							refw |= v << (8u * p);
 							const bool in =
-								LN.l_kind == 2 &&
-								(uint32_t)(LN.l_x - (int32_t)x8) < w8 &&
-								(uint32_t)(LN.l_y - (int32_t)y8) < h8;
+								CL_L_KIND(LN) == 2 &&
+								(uint32_t)(CL_L_X(LN) - (int32_t)x8) < w8 &&
+								(uint32_t)(CL_L_Y(LN) - (int32_t)y8) < h8;
 							LL[l] = in ? v : LL[l];
 						}
-						if (l)
-							refw1 = refw;
-						else
-							refw0 = refw;
+						H = cs_wl(H, refw, 16u + l);
 					}
 					CS_T(6);
 #pragma unroll
@@ -1371,9 +1402,9 @@ cs_slice_data(CbEng &c, WaveBits &wb, CbCtx &x, uint8_t *stage, uint8_t *row,
 									mv[k] = sv & 0xffffu;
 									const uint32_t am = m < 255u ? m : 255u;
 									const bool in =
-										LN.l_kind == k &&
-										(uint32_t)(LN.l_x - (int32_t)x4) < w4 &&
-										(uint32_t)(LN.l_y - (int32_t)y4) < h4;
+										CL_L_KIND(LN) == k &&
+										(uint32_t)(CL_L_X(LN) - (int32_t)x4) < w4 &&
+										(uint32_t)(CL_L_Y(LN) - (int32_t)y4) < h4;
 									LL[l] = in ? am : LL[l];
 								}
 								if (!ok)
@@ -1454,8 +1485,8 @@ cs_slice_data(CbEng &c, WaveBits &wb, CbCtx &x, uint8_t *stage, uint8_t *row,
 					for (uint32_t q = 0; q < 3; q++) {
 						if (q >= ncomp)
 							continue;
-						G[q] = cs_grid_open(G[q], LN.g_role,
-								    LN.g_off + 4u * q, LN.g_src,
+						G[q] = cs_grid_open(G[q], CL_G_ROLE(LN),
+								    CL_G_OFF(LN) + 4u * q, CL_G_SRC(LN),
 								    rowent, vA != 0, vB != 0, fill);
 					}
 					/* an 8x8 block coded with its own flag (4:4:4) only
@@ -1466,8 +1497,8 @@ cs_slice_data(CbEng &c, WaveBits &wb, CbCtx &x, uint8_t *stage, uint8_t *row,
 						const bool okB = !vB || (nbB & (CS_NB_T8 | CS_NB_PCM));
 #pragma unroll
 						for (uint32_t q = 0; q < 3; q++) {
-							G[q] = (LN.g_role & CS_ROLE_LEFT) && !okA ? 0u : G[q];
-							G[q] = (LN.g_role & CS_ROLE_TOP) && !okB ? 0u : G[q];
+							G[q] = (CL_G_ROLE(LN) & CS_ROLE_LEFT) && !okA ? 0u : G[q];
+							G[q] = (CL_G_ROLE(LN) & CS_ROLE_TOP) && !okB ? 0u : G[q];
 						}
 					}
 					CS_T(10);
@@ -1647,7 +1678,7 @@ cs_slice_data(CbEng &c, WaveBits &wb, CbCtx &x, uint8_t *stage, uint8_t *row,
 					/* only the inside of a grid travels on */
 #pragma unroll
 					for (uint32_t q = 0; q < 3; q++)
-						G[q] = (LN.g_role & CS_ROLE_IN) && q < ncomp ? G[q] : 0u;
+						G[q] = (CL_G_ROLE(LN) & CS_ROLE_IN) && q < ncomp ? G[q] : 0u;
 				} else {
 					prev_qpd_nz = 0;
 					G[0] = G[1] = G[2] = 0;
@@ -1661,10 +1692,6 @@ cs_slice_data(CbEng &c, WaveBits &wb, CbCtx &x, uint8_t *stage, uint8_t *row,
 				    : lane == 1
 					    ? (((uint32_t)qpd & 0xffffu) | (icp << 16) |
 					       (i16pred << 24))
-				    : lane == 2	 ? pred_lo
-				    : lane == 3	 ? pred_hi
-				    : lane == 16 ? refw0
-				    : lane == 17 ? refw1
 						 : H;
 				nz_bytes = true;
 				nz_val = NZ;
@@ -1689,18 +1716,18 @@ cs_slice_data(CbEng &c, WaveBits &wb, CbCtx &x, uint8_t *stage, uint8_t *row,
 			if (lane < CS_ROW_STRIDE / 4u)
 				reinterpret_cast<uint32_t *>(rowent)[lane] = lane ? 0u : me;
 		} else {
-			const bool gb = (LN.g_role & CS_ROLE_BOT) != 0;
-			const bool lb = (LN.l_role & CS_ROLE_BOT) != 0;
+			const bool gb = (CL_G_ROLE(LN) & CS_ROLE_BOT) != 0;
+			const bool lb = (CL_L_ROLE(LN) & CS_ROLE_BOT) != 0;
 			if (gb) {
-				rowent[LN.g_off] = (uint8_t)G[0];
+				rowent[CL_G_OFF(LN)] = (uint8_t)G[0];
 				if (c444) {
-					rowent[LN.g_off + 4u] = (uint8_t)G[1];
-					rowent[LN.g_off + 8u] = (uint8_t)G[2];
+					rowent[CL_G_OFF(LN) + 4u] = (uint8_t)G[1];
+					rowent[CL_G_OFF(LN) + 8u] = (uint8_t)G[2];
 				}
 			}
 			if (!S.is_i && lb) {
-				rowent[LN.l_off] = (uint8_t)LL[0];
-				rowent[LN.l_off + 12u] = (uint8_t)LL[1];
+				rowent[CL_L_OFF(LN)] = (uint8_t)LL[0];
+				rowent[CL_L_OFF(LN) + 12u] = (uint8_t)LL[1];
 			}
 			if (lane == 0)
 				*reinterpret_cast<uint32_t *>(rowent) = me;
