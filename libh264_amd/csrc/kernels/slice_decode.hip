@@ -2466,7 +2466,7 @@ __device__ __forceinline__ void sd_one_slice(const sd_args &a, const uint32_t sl
  * same idea -- was built and measured: bit-exact, but the loop around the
  * slice body costs the register allocator 104 spilled vector registers (0
  * without it) and the bench batch 54.5 -> 61.8 ms, 5632 slices 101 -> 148 ms
- * (profiles/r03_decode_queue_ab.jsonl); laundering the table pointers against
+ * (profiles/r03_decode_ab_history.jsonl); laundering the table pointers against
  * hoisting, -disable-machine-licm and an out-of-line slice function did not
  * bring them back. */
 template <bool WITH_MBAFF>
