@@ -102,6 +102,9 @@ struct orc_rec {
 	uint32_t slice_index;
 	struct evvec events, sps, pps, headers, results, mbrecs, mboffs;
 	struct evvec rewrites, rewrite_idx, nals;
+	/* h264_reader_stop() from the nalu_end callback of the n-th NAL unit of
+	 * a parse (0: never) */
+	uint32_t stop_after, ends;
 };
 
 static void cb_au_end(struct orc_ctx *ctx, void *ud)
@@ -127,6 +130,8 @@ static void cb_nalu_end(struct orc_ctx *ctx, uint32_t type, const uint8_t *buf,
 	struct orc_rec *r = ud;
 	ev_push(&r->events, EV_NALU_END, type | (nh->nal_ref_idc << 8),
 		(uint64_t)(buf - r->base), len);
+	if (r->stop_after && ++r->ends == r->stop_after)
+		r->rd->stop = 1; /* h264_reader_stop (ref src/h264_reader.c:107-114) */
 	if ((r->want & ORC_REC_WANT_REWRITE) && !ctx->nalu.unknown) {
 		struct h264_bitstream bs;
 		struct orc_rewrite w;
@@ -387,7 +392,11 @@ int orc_rec_parse_stream(struct orc_rec *r, const uint8_t *buf, size_t len,
 	if (r == NULL || buf == NULL || off == NULL)
 		return -EINVAL;
 	*off = 0;
-	while (*off < len) {
+	r->rd->stop = 0;
+	r->ends = 0;
+	/* (the reference's loop looks at the stop flag where it looks at the
+	 * offset, src/h264_reader.c:133) */
+	while (*off < len && !r->rd->stop) {
 		struct h264_amd_nal n;
 		res = orc_find_nalu(buf + *off, len - *off, &start, &end);
 		if (res < 0 && res != -EAGAIN)
@@ -418,6 +427,11 @@ ACCESSOR(mboffs, mboffs, uint64_t)
 ACCESSOR(rewrites, rewrites, uint8_t)
 ACCESSOR(rewrite_idx, rewrite_idx, struct orc_rewrite)
 ACCESSOR(nals, nals, struct h264_amd_nal)
+
+void orc_rec_stop_after(struct orc_rec *r, uint32_t n)
+{
+	r->stop_after = n;
+}
 
 struct orc_ctx *orc_rec_ctx(struct orc_rec *r)
 {

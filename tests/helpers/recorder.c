@@ -36,6 +36,9 @@ struct rec {
 	uint32_t nal_index;
 	struct evvec events, sps, pps, headers, rewrites, rewrite_idx, dumps;
 	struct h264_dump *dump;
+	/* h264_reader_stop() from the nalu_end callback of the n-th NAL unit of
+	 * a parse (0: never) */
+	uint32_t stop_after, ends;
 };
 
 static void cb_au_end(struct h264_ctx *ctx, void *ud)
@@ -62,6 +65,8 @@ static void cb_nalu_end(struct h264_ctx *ctx, enum h264_nalu_type type,
 	struct rec *r = ud;
 	ev_push(&r->events, EV_NALU_END, type | (nh->nal_ref_idc << 8),
 		(uint64_t)(buf - r->base), len);
+	if (r->stop_after && ++r->ends == r->stop_after)
+		h264_reader_stop(r->rd);
 	if (r->want & REC_WANT_DUMP) {
 		const char *str = NULL;
 		char num[32];
@@ -274,12 +279,13 @@ int rec_parse_nalu(struct rec *r, const uint8_t *base, const uint8_t *buf,
 int rec_parse_stream(struct rec *r, const uint8_t *buf, size_t len, size_t *off)
 {
 	r->base = buf;
+	r->ends = 0;
 	return h264_reader_parse(r->rd, r->flags, buf, len, off);
 }
 
-int rec_stop_after(struct rec *r)
+void rec_stop_after(struct rec *r, uint32_t n)
 {
-	return h264_reader_stop(r->rd);
+	r->stop_after = n;
 }
 
 struct h264_ctx *rec_ctx(struct rec *r)

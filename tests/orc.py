@@ -117,14 +117,28 @@ class Recording:
         return a.reshape(n, stride)
 
 
-def parse_stream(data, flags=READER_FLAGS_SLICE_DATA, want=ORC_REC_WANT_T2):
+def parse_stream(data, flags=READER_FLAGS_SLICE_DATA, want=ORC_REC_WANT_T2,
+                 stop_after=0):
+    """stop_after = n: h264_reader_stop() from the nalu_end callback of the
+    n-th NAL unit; the parse is then taken up again, with the same reader, at
+    the offset it returned (consumed_first), to the end."""
     L = lib()
     rec = L.orc_rec_new(flags, want)
     off = C.c_size_t()
-    buf = bytes(data)
-    L.orc_rec_parse_stream(rec, buf, len(buf), C.byref(off))
+    buf = C.create_string_buffer(bytes(data), len(data))
+    L.orc_rec_stop_after.argtypes = [C.c_void_p, C.c_uint32]
+    L.orc_rec_stop_after.restype = None
+    L.orc_rec_stop_after(rec, stop_after)
+    L.orc_rec_parse_stream(rec, buf, len(data), C.byref(off))
+    first = off.value
+    if stop_after and first < len(data):
+        L.orc_rec_stop_after(rec, 0)
+        L.orc_rec_parse_stream(rec, C.c_char_p(C.addressof(buf) + first), len(data) - first,
+                               C.byref(off))
+        off.value += first
     out = Recording(rec, buf)
     out.consumed = off.value
+    out.consumed_first = first
     L.orc_rec_free(rec)
     return out
 

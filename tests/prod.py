@@ -125,14 +125,25 @@ class Recording:
         return [(e.kind, e.a, e.b, e.c) for e in self.events]
 
 
-def parse_stream(data, flags=READER_FLAGS_SLICE_DATA, want=0):
+def parse_stream(data, flags=READER_FLAGS_SLICE_DATA, want=0, stop_after=0):
+    """stop_after: as orc.parse_stream"""
     L = recorder()
     rec = L.rec_new(flags, want)
     off = C.c_size_t()
-    buf = bytes(data)
-    res = L.rec_parse_stream(rec, buf, len(buf), C.byref(off))
+    buf = C.create_string_buffer(bytes(data), len(data))
+    L.rec_stop_after.argtypes = [C.c_void_p, C.c_uint32]
+    L.rec_stop_after.restype = None
+    L.rec_stop_after(rec, stop_after)
+    res = L.rec_parse_stream(rec, buf, len(data), C.byref(off))
+    first = off.value
+    if stop_after and res == 0 and first < len(data):
+        L.rec_stop_after(rec, 0)
+        res = L.rec_parse_stream(rec, C.c_char_p(C.addressof(buf) + first), len(data) - first,
+                                 C.byref(off))
+        off.value += first
     out = Recording(rec, buf)
     out.consumed = off.value
+    out.consumed_first = first
     out.result = res
     L.rec_free(rec)
     return out

@@ -189,6 +189,26 @@ def test_reader_many_slices_chunks(monkeypatch):
     assert sum(1 for e in got.event_tuples() if e[0] == 7) == 6 * 8160
 
 
+@pytest.mark.parametrize("stop_after", [1, 2, 5, 9, 30])
+def test_reader_stop_and_resume(monkeypatch, stop_after):
+    """h264_reader_stop() from a nalu_end callback in the middle of a buffer
+    (ref src/h264_reader.c:107-114,133): the callbacks up to there, the offset
+    returned, and the rest of the buffer parsed with the same reader from that
+    offset -- with record pages of a few slices, so that a page is on its way
+    from the device when the parse is left."""
+    monkeypatch.setenv("H264_AMD_READER_CHUNK_BYTES", "30000")
+    cfg = streams.small_cfg()
+    nals = mixed_nals(cfg, n_slices=30, seed0=50)
+    data = streams.annexb(nals)
+    ref = orc.parse_stream(data, want=0, stop_after=stop_after)
+    got = prod.parse_stream(data, stop_after=stop_after)
+    assert got.result == 0
+    assert 0 < ref.consumed_first < len(data)
+    assert got.consumed_first == ref.consumed_first
+    assert got.consumed == ref.consumed
+    same_log(ref, got, stream=True)
+
+
 def test_dump_style_write_back():
     """The reference tool's check (tools/h264_dump.c:229-262): every NAL is
     re-written from nalu_end with h264_write_nalu and must reproduce its
