@@ -10,7 +10,7 @@ records and the per-slice checksum over the full macroblock syntax written
 back.  Inputs are resident in HBM before the timed region.
 
   python bench.py [--gpus N] [--steps K] [--warmup W] [--slices S]
-                  [--workload c2|c4] [--no-extras]
+                  [--workload c1|c2|c3|c4|c5] [--no-extras]
 
 N > 1: one process per GPU (torch.distributed, backend nccl = RCCL).  Started
 without a launcher (`python bench.py --gpus 8`) this process starts the N ranks
@@ -321,7 +321,7 @@ def side_measurements(eng, params, d_buf, descs, d_descs, sizes, buf, offs,
     return side
 
 
-def c3_real(eng, n, cores, reps):
+def c3_real(eng, n, cores, reps, steps=0, warmup=0):
     """BASELINE config 3 on real content: n 1080p High-profile CABAC P-slices
     with residual data from the generator's own arithmetic encoder
     (csrc/gen/h264gen_cabac.inc), decoded by h264_amd_k_decode_cabac (contexts
@@ -397,8 +397,24 @@ def c3_real(eng, n, cores, reps):
         ms_hdr.append(eng.last_kernel_ms("decode"))
     k_ms = float(np.median(ms))
     total = int(sizes.sum())
+    wall_ms = None
+    if steps:
+        # whole steps (header pass + CABAC pass), wall clock, inputs resident
+        for _ in range(warmup):
+            eng.decode_slices(params, d_buf, descs, reader_flags=0x101,
+                              tier=TIER_T0, mb_capacity=8160,
+                              want_headers=True, d_descs=d_descs, outputs=out)
+        eng.sync()
+        t1 = time.perf_counter()
+        for _ in range(steps):
+            eng.decode_slices(params, d_buf, descs, reader_flags=0x101,
+                              tier=TIER_T0, mb_capacity=8160,
+                              want_headers=True, d_descs=d_descs, outputs=out)
+        eng.sync()
+        wall_ms = 1e3 * (time.perf_counter() - t1) / steps
     return {
         "kernel": "h264_amd_k_decode_cabac", "slices": n,
+        "ms_per_step": None if wall_ms is None else round(wall_ms, 3),
         "workload": "BASELINE config 3 with REAL residual: %d 1080p "
                     "High-profile CABAC P-slices (8160 MBs each, mean %.0f "
                     "bits/MB, %.0f bins/MB; 25 %% skipped, 8x8 transform, "
@@ -423,6 +439,62 @@ def c3_real(eng, n, cores, reps):
             "sample": "%d of the same slices through the oracle's CABAC "
                       "decoder, %.2f s" % (verified, cpu_s)},
         "gen_seconds": round(gen_s, 1)}
+
+
+def run_c3(args, cores):
+    """BASELINE config 3 as a line of its own: --slices 1080p CABAC P-slices
+    with real residual on one GPU (what side.c3 of the default line holds)."""
+    import libh264_amd
+    eng = libh264_amd.Engine(0)
+    c3 = c3_real(eng, args.slices, cores, 10, steps=args.steps,
+                 warmup=args.warmup)
+    ms = c3["ms_per_step"]
+    traffic, traffic_src = None, None
+    try:
+        import glob
+        for f in sorted(glob.glob(os.path.join(ROOT, "profiles",
+                                               "r*_cabac_hbm_traffic.json"))):
+            t = json.load(open(f))
+            if t.get("slices") == args.slices:
+                traffic = t["hbm_bytes_per_launch"]
+                traffic_src = os.path.relpath(f, ROOT)
+    except (OSError, ValueError, KeyError):
+        traffic = None
+    alg = c3["bytes"] + 64 * args.slices + 4 * 8160 * args.slices
+    emit({
+        "metric": "bitstream_parsed_mbit_per_s",
+        "value": round(8e-3 * c3["bytes"] / ms, 1), "unit": "Mbit/s",
+        "n_gpus": 1, "steps": args.steps, "warmup": args.warmup,
+        "ms_per_step": ms, "higher_is_better": True, "scaling": "weak",
+        "vs_baseline": None, "dtype": "u8", "data": "synthetic",
+        "macroblocks_per_s": round(8160e3 * args.slices / ms, 1),
+        "bins_per_s": round(1e3 * c3["bins"] / ms, 1),
+        "config": {"workload": "C3: " + c3["workload"],
+                   "slices_per_gpu": args.slices, "bytes_per_gpu": c3["bytes"],
+                   "output_tier": "T0",
+                   "parallelism": "one slice per wavefront, one GPU"},
+        "roofline": {
+            "bound": "hbm", "kernel": "h264_amd_k_decode_cabac",
+            "achieved": round(alg / c3["ms"] / 1e6, 2), "peak": HBM_PEAK_GBS,
+            "unit": "GB/s",
+            "frac": round(alg / c3["ms"] / 1e6 / HBM_PEAK_GBS, 6),
+            "traffic": traffic, "traffic_source": traffic_src,
+            "kernel_ms": c3["ms"],
+            "algorithmic_bytes_read": c3["bytes"],
+            "algorithmic_bytes_written": 64 * args.slices + 4 * 8160 * args.slices,
+            "note": "binary arithmetic decoding is one serial chain per slice: "
+                    "the kernel is bound by what crosses the scalar register "
+                    "file (scalar instructions, lane reads and writes), about "
+                    "27 such operations per bin at 4.4-4.8 cycles each with "
+                    "four waves per SIMD (DESIGN.md (d)); not by HBM"},
+        "cpu_baseline": {
+            "value": c3["cpu_port_single_thread"]["mbit_per_s"],
+            "unit": "Mbit/s", "cores": 1, "kind": "port",
+            "mb_per_s": c3["cpu_port_single_thread"]["macroblocks_per_s"],
+            "sample": c3["cpu_port_single_thread"]["sample"]},
+        "parity": c3["parity"],
+        "verified_slices_vs_oracle": c3["verified_slices_vs_oracle"],
+        "gen_seconds": c3["gen_seconds"]})
 
 
 def run_c1(args, cores):
@@ -702,12 +774,14 @@ def run_c5(args, dist, rank, world, share, eng, params, d_buf, descs, d_descs,
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--workload", default="c2",
-                    choices=["c1", "c2", "c4", "c5"],
+                    choices=["c1", "c2", "c3", "c4", "c5"],
                     help="c2: batch of I-slices (BASELINE config 2, the "
                          "headline); c4: one mixed Annex-B stream through scan "
                          "+ scatter + decode + gather (config 4); c5: writer "
                          "round trip; c1: the h264-dump tool on one 1080p file "
-                         "beside the CPU port (config 1)")
+                         "beside the CPU port (config 1); c3: CABAC P-slices "
+                         "with real residual (config 3; also side.c3 of the "
+                         "default line)")
     ap.add_argument("--mib", type=int, default=64,
                     help="c4: stream size in MiB")
     ap.add_argument("--gpus", type=int, default=1)
@@ -730,6 +804,13 @@ def main():
         if args.gpus != 1:
             raise SystemExit("c1 is one file through one reader: --gpus 1")
         run_c1(args, 16)
+        return
+    if args.workload == "c3":
+        if args.gpus != 1 or "WORLD_SIZE" in os.environ:
+            raise SystemExit("c3 is measured on one GPU: --gpus 1 (slices are "
+                             "independent; the multi-GPU shape is c2's)")
+        keep_stdout_for_the_result()
+        run_c3(args, 16)
         return
     if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
         sys.exit(spawn_ranks(args))

@@ -60,3 +60,9 @@ def test_one_line_under_rccl_and_the_other_workloads():
                   "--warmup", "1")
     assert d["scaling"] == "strong" and d["n_gpus"] == 1
     assert d["verified_slices_vs_oracle"] >= 1
+    d = run_bench("--workload", "c3", "--slices", "64", "--steps", "2",
+                  "--warmup", "1")
+    assert d["roofline"]["kernel"] == "h264_amd_k_decode_cabac"
+    assert d["bins_per_s"] > 0 and d["ms_per_step"] >= d["roofline"]["kernel_ms"]
+    assert d["cpu_baseline"]["cores"] == 1 and d["cpu_baseline"]["kind"] == "port"
+    assert d["verified_slices_vs_oracle"] >= 1 and "spec-only" in d["parity"]
