@@ -363,6 +363,15 @@ H264_API int h264_amd_gather_nal_heads(struct h264_amd_engine *eng,
  * Needs d_headers. */
 #define H264_AMD_READER_FLAGS_CABAC 0x100u
 #define H264_AMD_READER_FLAGS_CABAC_SUBSET H264_AMD_READER_FLAGS_CABAC /* round-2 name */
+/* With H264_AMD_READER_FLAGS_CABAC: decode 4:4:4 streams written by x264 before
+ * its build 151 (the version is in the stream's user-data SEI).  Those builds
+ * chose the coded_block_flag context of an 8x8 block next to a macroblock
+ * WITHOUT the 8x8 transform as if the neighbour were not available, where
+ * 9.3.3.1.1.9 says "transBlockN not available: condTermFlagN = 0"; a decoder
+ * that follows the standard loses such a stream at the first macroblock of
+ * that kind (libavcodec reproduces the old behaviour for these streams).  Off
+ * by default: the standard's rule. */
+#define H264_AMD_READER_FLAGS_CABAC_X264_PRE151 0x200u
 struct h264_amd_decode_args {
 	const uint8_t *d_buf; /* NAL bytes */
 	const struct h264_amd_slice_desc *d_descs; /* [n] */

@@ -160,6 +160,7 @@ struct cs_args {
 	 * 0: no priority rotation */
 	uint32_t prio_div;
 	const uint32_t *order; /* launch position -> slice, or NULL */
+	uint32_t quirks; /* bit 0: 4:4:4 streams of x264 before build 151 */
 };
 
 __device__ __forceinline__ uint32_t cb_hdr(const struct h264_slice_header *h,
@@ -670,6 +671,7 @@ struct CbSlice {
 	uint32_t type, cat, W, field, t8mode, direct8x8, bdl, bdc, pcm_chroma;
 	uint32_t nref0, nref1;
 	uint32_t is_b, is_i, is_si;
+	uint32_t x264_444; /* H264_AMD_READER_FLAGS_CABAC_X264_PRE151 */
 };
 
 /* ---- phase timers (diagnostic build only: -DCS_PHASE_TIMERS) -----------------
@@ -1493,12 +1495,23 @@ cs_slice_data(CbEng &c, WaveBits &wb, CbCtx &x, uint8_t *stage, uint8_t *row,
 					 * counts a neighbouring MACROBLOCK that was
 					 * transformed 8x8 (or is I_PCM) */
 					if (c444 && t8) {
-						const bool okA = !vA || (nbA & (CS_NB_T8 | CS_NB_PCM));
-						const bool okB = !vB || (nbB & (CS_NB_T8 | CS_NB_PCM));
+						bool okA = !vA || (nbA & (CS_NB_T8 | CS_NB_PCM));
+						bool okB = !vB || (nbB & (CS_NB_T8 | CS_NB_PCM));
+						uint32_t off = 0;
+						if (S.x264_444) {
+							/* x264 before build 151 treated such a
+							 * neighbour as if it were not there
+							 * (libavcodec reproduces it for those
+							 * streams, h264_cabac.c); not the
+							 * standard, on request only */
+							okA = !vA || (nbA & CS_NB_T8);
+							okB = !vB || (nbB & CS_NB_T8);
+							off = fill;
+						}
 #pragma unroll
 						for (uint32_t q = 0; q < 3; q++) {
-							G[q] = (CL_G_ROLE(LN) & CS_ROLE_LEFT) && !okA ? 0u : G[q];
-							G[q] = (CL_G_ROLE(LN) & CS_ROLE_TOP) && !okB ? 0u : G[q];
+							G[q] = (CL_G_ROLE(LN) & CS_ROLE_LEFT) && !okA ? off : G[q];
+							G[q] = (CL_G_ROLE(LN) & CS_ROLE_TOP) && !okB ? off : G[q];
 						}
 					}
 					CS_T(10);
@@ -1820,6 +1833,7 @@ h264_amd_k_decode_cabac(cs_args a)
 	S.nref0 = cb_hdr(hdr, WOFF(num_ref_idx_l0_active_minus1));
 	S.nref1 = cb_hdr(hdr, WOFF(num_ref_idx_l1_active_minus1));
 	S.t8mode = S.direct8x8 = 0;
+	S.x264_444 = 0;
 	S.bdl = S.bdc = 8;
 	S.pcm_chroma = 0;
 	if (status == 0) {
@@ -1828,6 +1842,7 @@ h264_amd_k_decode_cabac(cs_args a)
 		    P.pps.num_slice_groups_minus1 > 0 || S.W == 0 || S.W > a.row_pitch)
 			status = H264_AMD_E_UNSUPPORTED;
 		S.t8mode = P.pps.transform_8x8_mode_flag;
+		S.x264_444 = a.quirks & 1u;
 		S.direct8x8 = P.sps.direct_8x8_inference_flag;
 		S.bdl = P.sps.bit_depth_luma;
 		S.bdc = P.sps.bit_depth_chroma;

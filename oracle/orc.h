@@ -348,6 +348,7 @@ void orc_cabac_init_states(int slice_type, uint32_t cabac_init_idc,
  * what the reference's writers emit): CABAC slice data, orc_cabac_dec.c */
 int orc_cabac_slice_data(struct h264_bitstream *bs, struct orc_reader *rd);
 extern uint64_t orc_stat_cabac_bins; /* bins decoded (bench statistics) */
+extern int orc_quirk_x264_444_cbf; /* decode 4:4:4 streams of x264 < build 151 (test only) */
 extern uint64_t orc_stat_cabac_hist[1026]; /* by ctxIdx; 1024 bypass, 1025 terminate */
 int orc_write_grey_i_slice(struct h264_bitstream *bs, struct orc_ctx *ctx,
 			   uint32_t mb_count);

@@ -44,6 +44,7 @@
 #define EGK_MAX 24u /* prefix bits of an Exp-Golomb escape before -EIO */
 
 uint64_t orc_stat_cabac_bins;
+int orc_quirk_x264_444_cbf; /* see cbf_cond() */
 /* bins by kind (bench statistics): [ctxIdx] for decisions, [1024] bypass,
  * [1025] terminate */
 uint64_t orc_stat_cabac_hist[1026];
@@ -769,6 +770,13 @@ static uint32_t cbf_cond(const struct cd *c, uint32_t addrN, uint32_t kind,
 	if (addrN == ORC_MB_ADDR_INVALID)
 		return is_intra_type(c->mb->mb_type) ? 1 : 0;
 	n = info_of(c, addrN);
+	/* x264 before build 151 coded the coded_block_flag of an 8x8 block of a
+	 * 4:4:4 macroblock next to a macroblock WITHOUT the 8x8 transform as if
+	 * that neighbour were not there (what libavcodec's h264_cabac.c
+	 * reproduces for streams of those builds).  Not the standard: off unless
+	 * a test that decodes such a stream switches it on. */
+	if (orc_quirk_x264_444_cbf && kind == TB_8x8 && !n->t8)
+		return is_intra_type(c->mb->mb_type) ? 1 : 0;
 	if (n->mbt == H264_MB_TYPE_I_PCM)
 		return 1;
 	if (n->skipped)
