@@ -318,6 +318,23 @@ def side_measurements(eng, params, d_buf, descs, d_descs, sizes, buf, offs,
         "bins_per_s": round(2 * 8160e3 * n / k_ms, 1)}
     del d3, out4
     side["c3"] = c3_real(eng, n, cores, reps)
+    # the same kernel on a real encoder's output, where the image has such a
+    # file (tools/bench_cabac_clip.py; nothing in the repository depends on it)
+    try:
+        sys.path.insert(0, os.path.join(ROOT, "tools"))
+        import bench_cabac_clip
+        clip = bench_cabac_clip.measure(bench_cabac_clip.default_clip(),
+                                        eng=eng)
+        if clip is not None:
+            clip["workload"] = ("a real stream: the %d pictures of %s (x264, "
+                                "High 4:4:4 Predictive, 1280 x 720, I / P / B), "
+                                "%d copies in one launch, every slice complete "
+                                "and its checksum equal to the oracle's" %
+                                (clip["slices"] // clip["copies"], clip["clip"],
+                                 clip["copies"]))
+            side["c3_x264_clip"] = clip
+    except Exception as e:  # a side line never fails the bench
+        side["c3_x264_clip"] = {"skipped": str(e)[:200]}
     return side
 
 
