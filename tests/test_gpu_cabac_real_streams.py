@@ -77,3 +77,25 @@ def test_drop_in_library_on_real_streams(name, tmp_path):
     for k in range(len(nals)):
         json.loads(lines[2 * k])
         assert lines[2 * k + 1] == "OK", (k, nals[k][0] & 31)
+
+
+def test_damaged_real_slices(engine):
+    """bit flips, truncations and splices of the real slices: kernel and
+    oracle end every one of them the same way (status, macroblocks before the
+    error, checksum)"""
+    import random
+    from test_gpu_fuzz import mutate
+    rnd = random.Random(2024)
+    head, nals = slices_of(sample("cockatoo.mp4"))
+    head2, nals2 = slices_of(sample("realshort.mp4"))
+    picked = [nals[k] for k in range(0, 280, 7)]
+    bad = [mutate(n, rnd) for n in picked for _ in range(3)]
+    for flags, q in ((FLAGS, False),
+                     (FLAGS | READER_FLAGS_CABAC_X264_PRE151, True)):
+        try:
+            quirk(q)
+            compare(engine, head, bad, tier=TIER_T0, cap=3602, flags=flags)
+        finally:
+            quirk(False)
+    bad2 = [mutate(n, rnd) for n in nals2 for _ in range(4)]
+    compare(engine, head2, bad2, tier=TIER_T2, cap=302, flags=FLAGS)
