@@ -22,4 +22,5 @@ run dropin python3 tools/fuzz_dropin.py $base 100000 &&
 run dropin_params python3 tools/fuzz_dropin.py $base 100000 params &&
 run params python3 tools/fuzz_params.py $base 100000 &&
 run cabac_full python3 tools/fuzz_cabac_full.py $base 100000 &&
+run cabac_real python3 tools/fuzz_cabac_real.py $base 100000 &&
 run scan python3 tools/fuzz_scan.py $base 100000
