@@ -1515,7 +1515,13 @@ cs_slice_data(CbEng &c, WaveBits &wb, CbCtx &x, uint8_t *stage, uint8_t *row,
 						}
 					}
 					CS_T(10);
-					for (uint32_t comp = 0; comp < ncomp; comp++) {
+					/* the three colour components of 4:4:4 as three copies of the
+					 * code, each naming its own registers (a loop that rotates
+					 * the register sets costs moves and spills at its head) */
+#pragma unroll
+					for (uint32_t comp = 0; comp < 3; comp++) {
+						if (comp >= ncomp)
+							break;
 						const uint32_t cbase = 256u * comp;
 						if (i16) {
 							/* Intra16x16DCLevel */
@@ -1523,12 +1529,12 @@ cs_slice_data(CbEng &c, WaveBits &wb, CbCtx &x, uint8_t *stage, uint8_t *row,
 								vA ? (nbA >> (16u + comp)) & 1u : fill;
 							const uint32_t dB =
 								vB ? (nbB >> (16u + comp)) & 1u : fill;
-							if (cs_dec(c, wb, x.m8[0],
+							if (cs_dec(c, wb, x.m8[comp],
 								   CXL_CBF + 0u + dA + 2u * dB)) {
 								CS_T(11);
 								uint32_t cf = cs_block<false, false>(
-									c, wb, x.sig[0], x.last[0],
-									x.abs[0], 0, 0, 16, 1, ok CS_TPASS);
+									c, wb, x.sig[comp], x.last[comp],
+									x.abs[comp], 0, 0, 16, 1, ok CS_TPASS);
 								if (lane < 16u)
 									*reinterpret_cast<uint16_t *>(
 										stage + H264_AMD_T2_HEAD +
@@ -1547,15 +1553,15 @@ cs_slice_data(CbEng &c, WaveBits &wb, CbCtx &x, uint8_t *stage, uint8_t *row,
 								uint32_t coded = 1;
 								if (c444)
 									coded = cs_dec(
-										c, wb, x.m8[0],
+										c, wb, x.m8[comp],
 										CXL_CBF8 +
-											cs_rl(G[0], cs_g5(x4 - 1u, y4)) +
-											2u * cs_rl(G[0], cs_g5(x4, y4 - 1u)));
+											cs_rl(G[comp], cs_g5(x4 - 1u, y4)) +
+											2u * cs_rl(G[comp], cs_g5(x4, y4 - 1u)));
 								if (!coded)
 									continue;
 								CS_T(11);
 								uint32_t cf = cs_block<true, false>(
-									c, wb, x.m8[0], x.m8[0], x.abs[0],
+									c, wb, x.m8[comp], x.m8[comp], x.abs[comp],
 									0, CXL_ABS8, 64, 1, ok CS_TPASS);
 								/* 4x4 view of the record: coefficient
 								 * 4 k + j is coefficient k of array j */
@@ -1572,10 +1578,10 @@ cs_slice_data(CbEng &c, WaveBits &wb, CbCtx &x, uint8_t *stage, uint8_t *row,
 											   nzm & (0x1111111111111111ull << j)),
 										   16u * comp + 4u * b8 + j);
 								const uint32_t gl = cs_g5(x4, y4);
-								G[0] = (lane == gl || lane == gl + 1u ||
+								G[comp] = (lane == gl || lane == gl + 1u ||
 									lane == gl + 5u || lane == gl + 6u)
 									       ? 1u
-									       : G[0];
+									       : G[comp];
 								CS_T(14);
 							}
 						} else {
@@ -1586,21 +1592,21 @@ cs_slice_data(CbEng &c, WaveBits &wb, CbCtx &x, uint8_t *stage, uint8_t *row,
 								const uint32_t x4 = (b & 1u) | ((b >> 1) & 2u);
 								const uint32_t y4 = ((b >> 1) & 1u) | ((b >> 2) & 2u);
 								const uint32_t inc =
-									cs_rl(G[0], cs_g5(x4 - 1u, y4)) +
-									2u * cs_rl(G[0], cs_g5(x4, y4 - 1u));
-								if (!cs_dec(c, wb, x.m8[0],
+									cs_rl(G[comp], cs_g5(x4 - 1u, y4)) +
+									2u * cs_rl(G[comp], cs_g5(x4, y4 - 1u));
+								if (!cs_dec(c, wb, x.m8[comp],
 									    CXL_CBF + (i16 ? 4u : 8u) + inc))
 									continue;
 								CS_T(11);
 								uint32_t cf;
 								if (i16)
 									cf = cs_block<false, false>(
-										c, wb, x.sig[0], x.last[0],
-										x.abs[0], 15, 10, 15, 1, ok CS_TPASS);
+										c, wb, x.sig[comp], x.last[comp],
+										x.abs[comp], 15, 10, 15, 1, ok CS_TPASS);
 								else
 									cf = cs_block<false, false>(
-										c, wb, x.sig[0], x.last[0],
-										x.abs[0], 29, 20, 16, 1, ok CS_TPASS);
+										c, wb, x.sig[comp], x.last[comp],
+										x.abs[comp], 29, 20, 16, 1, ok CS_TPASS);
 								const uint32_t numc = i16 ? 15u : 16u;
 								if (lane < numc)
 									*reinterpret_cast<uint16_t *>(
@@ -1613,18 +1619,9 @@ cs_slice_data(CbEng &c, WaveBits &wb, CbCtx &x, uint8_t *stage, uint8_t *row,
 										   __builtin_amdgcn_ballot_w64(
 											   (cf & 0xffffu) != 0)),
 									   16u * comp + b);
-								G[0] = lane == cs_g5(x4, y4) ? 1u : G[0];
+								G[comp] = lane == cs_g5(x4, y4) ? 1u : G[comp];
 								CS_T(14);
 							}
-						}
-						if (c444) {
-							/* next component: its contexts and its
-							 * grid move to position 0 */
-							cs_rot3(x.sig);
-							cs_rot3(x.last);
-							cs_rot3(x.abs);
-							cs_rot3(x.m8);
-							cs_rot3(G);
 						}
 					}
 					if (c12) {
