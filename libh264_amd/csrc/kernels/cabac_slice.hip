@@ -36,8 +36,9 @@
  *   * the 64 dwords of a T2 record's head are one register (v_writelane per
  *     field), the coefficients of the block being decoded another (lane =
  *     scanning position), stored with one ds_write per lane;
- *   * with ChromaArrayType 3 the per-component register sets rotate at the
- *     component switch, so the residual code exists once.
+ *   * with ChromaArrayType 3 the residual code exists once per colour component,
+ *     each copy naming that component's registers (a loop that rotated the
+ *     sets cost moves and 16 spilled registers).
  */
 #ifndef H264_AMD_CABAC_SLICE_HIP
 #define H264_AMD_CABAC_SLICE_HIP
@@ -518,14 +519,6 @@ struct CbCtx {
 	uint32_t mb0, mb1;
 	uint32_t sig[3], last[3], abs[3], m8[3];
 };
-
-__device__ __forceinline__ void cs_rot3(uint32_t (&r)[3])
-{
-	uint32_t t = r[0];
-	r[0] = r[1];
-	r[1] = r[2];
-	r[2] = t;
-}
 
 /* ---- per-lane roles in the neighbour grids ---------------------------------- */
 #define CS_ROLE_TOP 1u /* border: the macroblock above */
