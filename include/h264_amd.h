@@ -372,6 +372,10 @@ H264_API int h264_amd_gather_nal_heads(struct h264_amd_engine *eng,
  * that kind (libavcodec reproduces the old behaviour for these streams).  Off
  * by default: the standard's rule. */
 #define H264_AMD_READER_FLAGS_CABAC_X264_PRE151 0x200u
+/* The x264 build number out of a user-data SEI NAL unit ("x264 - core NNN"), 0
+ * if there is none: a caller sets the flag above for ChromaArrayType 3 streams
+ * with 0 < build < 151. */
+H264_API uint32_t h264_amd_x264_build(const uint8_t *sei_nal, size_t len);
 struct h264_amd_decode_args {
 	const uint8_t *d_buf; /* NAL bytes */
 	const struct h264_amd_slice_desc *d_descs; /* [n] */

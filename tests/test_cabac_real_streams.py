@@ -124,3 +124,20 @@ def test_x264_444_stream_with_b_slices_and_weighted_prediction():
     # its first Intra16x16 macroblock (no 8x8 transform) among Intra8x8 ones
     ref = orc.parse_nalus(head + nals[:1], flags=FLAGS, want=0)
     assert ref.results[0].mb_count < pic
+
+
+def test_x264_build_number_from_the_sei():
+    """h264_amd_x264_build (include/h264_amd.h): what a caller keys
+    H264_AMD_READER_FLAGS_CABAC_X264_PRE151 to"""
+    import ctypes as C
+    from libh264_amd import capi
+    L = capi.engine_lib()
+    L.h264_amd_x264_build.restype = C.c_uint32
+    L.h264_amd_x264_build.argtypes = [C.c_char_p, C.c_size_t]
+    sps, pps, samples = mp4_demux.video_nals(sample("cockatoo.mp4"))
+    sei = [bytes(n) for n in samples[0] if (n[0] & 31) == 6][0]
+    assert L.h264_amd_x264_build(sei, len(sei)) == 142
+    idr = [bytes(n) for n in samples[0] if (n[0] & 31) == 5][0]
+    assert L.h264_amd_x264_build(idr, len(idr)) == 0
+    assert L.h264_amd_x264_build(b"\x06\x05x264 - core 164 r3095", 24) == 164
+    assert L.h264_amd_x264_build(b"\x06", 1) == 0
