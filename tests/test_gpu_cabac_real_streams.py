@@ -99,3 +99,39 @@ def test_damaged_real_slices(engine):
             quirk(False)
     bad2 = [mutate(n, rnd) for n in nals2 for _ in range(4)]
     compare(engine, head2, bad2, tier=TIER_T2, cap=302, flags=FLAGS)
+
+
+def test_against_committed_expectations(engine):
+    """the kernel alone against tests/golden/real_streams_expect.json (made by
+    tests/golden/make_real_expect.py from the oracle's decoder; the clips are
+    identified by SHA-256): the oracle is not consulted here"""
+    import hashlib
+    import json
+    import os
+    import numpy as np
+    import orc
+    import streams
+    from libh264_amd import Params
+    exp = json.load(open(os.path.join(os.path.dirname(__file__), "golden",
+                                      "real_streams_expect.json")))
+    for name, e in exp.items():
+        path = sample(name)
+        if hashlib.sha256(open(path, "rb").read()).hexdigest() != e["sha256"]:
+            pytest.skip("another %s than the one the expectations are for" % name)
+        head, nals = slices_of(path)
+        ps = orc.parse_nalus(head, flags=0, want=0)  # parameter sets only
+        params = Params()
+        params.put_sps(ps.sps[0])
+        epoch = params.put_pps(ps.pps[0])
+        buf, offs, sizes = streams.pack_nals(nals)
+        cap = max(r[1] for r in e["slices"]) + 2
+        flags = FLAGS | (READER_FLAGS_CABAC_X264_PRE151
+                         if e["x264_before_151"] else 0)
+        out = engine.decode_slices(
+            params, engine.upload(buf),
+            [(o, z, epoch) for o, z in zip(offs, sizes)], reader_flags=flags,
+            tier=TIER_T0, mb_capacity=cap, want_headers=True)
+        res = engine.fetch_results(out)
+        got = [[r.status, r.mb_count, r.end_bit, "%016x" % r.checksum]
+               for r in res]
+        assert got == e["slices"], name
