@@ -357,7 +357,9 @@ H264_API int h264_amd_gather_nal_heads(struct h264_amd_engine *eng,
  * coefficient k of the 4x4 array j of its quadrant (the interleaving CAVLC
  * uses, ref src/h264_syntax_slice_data.h:323-326); nz_coeff[] counts the
  * non-zero coefficients of each 4x4 array, DC blocks not counted; a level
- * beyond 16 bits wraps; unary codes are bounded (mb_qp_delta, ref_idx: 255;
+ * beyond 16 bits wraps, and so does a motion vector difference, whose
+ * neighbours' contexts see the magnitude of the 16-bit value as stored; unary
+ * codes are bounded (mb_qp_delta, ref_idx: 255;
  * Exp-Golomb escapes: 24 prefix bits) and end the slice with -EIO beyond; so
  * does a start of the decoding engine with codIOffset 510 or 511 (9.3.1.2).
  * Needs d_headers. */

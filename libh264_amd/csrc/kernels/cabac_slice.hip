@@ -1395,7 +1395,14 @@ cs_slice_data(CbEng &c, WaveBits &wb, CbCtx &x, uint8_t *stage, uint8_t *row,
 									if (m && cs_bypass(c, wb))
 										sv = 0u - m;
 									mv[k] = sv & 0xffffu;
-									const uint32_t am = m < 255u ? m : 255u;
+									/* what the neighbours' contexts see is the
+									 * magnitude of the value as it is STORED, 16
+									 * bits (a damaged stream can carry more; the
+									 * oracle keeps an int16_t like the
+									 * reference's macroblock struct) */
+									const int32_t sw = (int16_t)(sv & 0xffffu);
+									const uint32_t aw = (uint32_t)(sw < 0 ? -sw : sw);
+									const uint32_t am = aw < 255u ? aw : 255u;
 									const bool in =
 										CL_L_KIND(LN) == k &&
 										(uint32_t)(CL_L_X(LN) - (int32_t)x4) < w4 &&

@@ -135,3 +135,21 @@ def test_against_committed_expectations(engine):
         got = [[r.status, r.mb_count, r.end_bit, "%016x" % r.checksum]
                for r in res]
         assert got == e["slices"], name
+
+
+def test_fuzz_seeds_that_found_something(engine):
+    """tools/fuzz_cabac_real.py seeds kept as regressions.  130473: a damaged P
+    slice whose motion vector difference no longer fits 16 bits -- the contexts
+    of the neighbouring blocks see the magnitude of the STORED value (int16_t,
+    as in the reference's macroblock struct), the kernel used the unwrapped
+    one."""
+    import os
+    import sys
+    sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(
+        os.path.abspath(__file__))), "tools"))
+    import fuzz_cabac_real as fr
+    sample("cockatoo.mp4")
+    sample("realshort.mp4")
+    clips = fr.load_clips()
+    for seed in (130473,):
+        fr.one(engine, clips, seed)

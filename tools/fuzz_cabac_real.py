@@ -30,31 +30,40 @@ def clip(name):
     return slices_of(c[0])
 
 
+def load_clips():
+    return [clip("cockatoo.mp4") + (3602,), clip("realshort.mp4") + (302,)]
+
+
+def one(eng, clips, seed):
+    """one seed: raises AssertionError on a divergence"""
+    rnd = random.Random(seed)
+    head, nals, cap = clips[rnd.randrange(2)]
+    pick = [rnd.choice(nals) for _ in range(24)]
+    batch = [n if rnd.randrange(4) == 0 else mutate(n, rnd) for n in pick]
+    q = rnd.randrange(2) == 1
+    flags = 0x101 | (0x200 if q else 0)
+    tier = rnd.choice([TIER_T0, TIER_T0, TIER_T1, TIER_NONE] +
+                      ([TIER_T2] if cap < 1000 else []))
+    try:
+        quirk(q)
+        compare(eng, head, batch, tier=tier, cap=rnd.choice([cap, cap, 50]),
+                flags=flags, lead=seed % 4)
+    finally:
+        quirk(False)
+
+
 def main():
     first = int(sys.argv[1]) if len(sys.argv) > 1 else 1
     count = int(sys.argv[2]) if len(sys.argv) > 2 else 100
     eng = libh264_amd.Engine(0)
-    clips = [clip("cockatoo.mp4") + (3602,), clip("realshort.mp4") + (302,)]
+    clips = load_clips()
     bad = 0
     for seed in range(first, first + count):
-        rnd = random.Random(seed)
-        head, nals, cap = clips[rnd.randrange(2)]
-        pick = [rnd.choice(nals) for _ in range(24)]
-        batch = [n if rnd.randrange(4) == 0 else mutate(n, rnd) for n in pick]
-        q = rnd.randrange(2) == 1
-        flags = 0x101 | (0x200 if q else 0)
-        tier = rnd.choice([TIER_T0, TIER_T0, TIER_T1, TIER_NONE] +
-                          ([TIER_T2] if cap < 1000 else []))
         try:
-            quirk(q)
-            compare(eng, head, batch, tier=tier,
-                    cap=rnd.choice([cap, cap, 50]), flags=flags,
-                    lead=seed % 4)
+            one(eng, clips, seed)
         except AssertionError as e:
-            print("seed %d: %s" % (seed, str(e)[:300]), flush=True)
+            print("seed %d: %s" % (seed, str(e)[:int(os.environ.get("FUZZ_MSG", "300"))]), flush=True)
             bad += 1
-        finally:
-            quirk(False)
         if (seed - first) % 50 == 49:
             print("... %d seeds, %d divergences" % (seed - first + 1, bad),
                   flush=True)
