@@ -378,6 +378,14 @@ H264_API int h264_amd_gather_nal_heads(struct h264_amd_engine *eng,
  * if there is none: a caller sets the flag above for ChromaArrayType 3 streams
  * with 0 < build < 151. */
 H264_API uint32_t h264_amd_x264_build(const uint8_t *sei_nal, size_t len);
+/* With H264_AMD_READER_FLAGS_CABAC: initialise the context variables with
+ * SliceQPY clipped to 0..51 as 9.3.1.1 says, not to 1..51 as the reference's
+ * encoder does.  The two differ at SliceQPY 0 only (and below, which no
+ * conforming 8-bit stream reaches): a slice the reference's writers -- or this
+ * library's -- made at SliceQPY 0 needs the default, a slice of any other
+ * encoder at SliceQPY 0 (lossless x264, qpprime_y_zero_transform_bypass_flag)
+ * needs this flag. */
+#define H264_AMD_READER_FLAGS_CABAC_STD_QP 0x400u
 struct h264_amd_decode_args {
 	const uint8_t *d_buf; /* NAL bytes */
 	const struct h264_amd_slice_desc *d_descs; /* [n] */

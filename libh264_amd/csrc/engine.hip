@@ -910,7 +910,8 @@ extern "C" int h264_amd_decode_slices(struct h264_amd_engine *e,
 				      ? a.row_pitch
 				      : H264_AMD_MAX_CABAC_WIDTH_MBS;
 		c.order = a.order;
-		c.quirks = (args->reader_flags & H264_AMD_READER_FLAGS_CABAC_X264_PRE151) ? 1u : 0u;
+		c.quirks = ((args->reader_flags & H264_AMD_READER_FLAGS_CABAC_X264_PRE151) ? 1u : 0u) |
+			   ((args->reader_flags & H264_AMD_READER_FLAGS_CABAC_STD_QP) ? 2u : 0u);
 		c.wave_lds_bytes =
 			(CS_ROW_OFF + CS_ROW_STRIDE * c.row_pitch + 255u) & ~255u;
 		{

@@ -1675,7 +1675,8 @@ int h264gen_slice_nal(const struct h264gen_cfg *cfg,
 		g.ce.w = &g.w;
 		ce_start(&g.ce);
 		ce_init_states(&g.ce, g.st == 2, sl->cabac_init_idc,
-			       26 + cfg->pic_init_qp_minus26 + sl->slice_qp_delta);
+			       26 + cfg->pic_init_qp_minus26 + sl->slice_qp_delta,
+			       sl->cabac_syntax == 2 ? 0 : 1);
 	}
 	if (cfg->num_slice_groups_minus1 > 0) {
 		/* the slice codes macroblocks of first_mb's group, in address

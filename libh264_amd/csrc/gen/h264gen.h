@@ -89,7 +89,10 @@ struct h264gen_slice {
 	uint32_t slice_group_change_cycle; /* slice group map types 3..5 */
 	/* CABAC PPS: 1 = real macroblock syntax through the generator's own
 	 * arithmetic encoder (h264gen_cabac.inc; frame and field pictures, no
-	 * MBAFF); 0 = cabac_payload bytes of opaque slice data */
+	 * MBAFF), 2 = the same with the context variables of a slice at
+	 * SliceQPY 0 initialised as the standard says (9.3.1.1: QP clipped
+	 * to 0..51) instead of the reference's way (1..51, src/h264_bac.c:
+	 * 216-230); 0 = cabac_payload bytes of opaque slice data */
 	uint32_t cabac_syntax;
 	uint64_t seed;
 };

@@ -161,7 +161,8 @@ struct cs_args {
 	 * 0: no priority rotation */
 	uint32_t prio_div;
 	const uint32_t *order; /* launch position -> slice, or NULL */
-	uint32_t quirks; /* bit 0: 4:4:4 streams of x264 before build 151 */
+	uint32_t quirks; /* bit 0: 4:4:4 streams of x264 before build 151;
+			  * bit 1: context variables at SliceQPY 0 per the standard */
 };
 
 __device__ __forceinline__ uint32_t cb_hdr(const struct h264_slice_header *h,
@@ -1874,14 +1875,19 @@ h264_amd_k_decode_cabac(cs_args a)
 			const uint32_t idc = cb_hdr(hdr, WOFF(cabac_init_idc));
 			const bool valid = S.is_i || idc <= 2;
 			const uint32_t col = S.is_i ? 0u : 1u + (valid ? idc : 0u);
+			/* SliceQPY clipped the reference's way, or the standard's
+			 * (quirk bit 1, H264_AMD_READER_FLAGS_CABAC_STD_QP) */
+			const int32_t qlo = (a.quirks & 2u) ? 0 : 1;
+			const int32_t iq = r.slice_qp < qlo ? qlo :
+					   r.slice_qp > 51 ? 51 : r.slice_qp;
 			uint32_t regs[CX_REGS];
 #pragma unroll
 			for (uint32_t q = 0; q < CX_REGS; q++) {
 				const uint32_t ci = a.dtab->slot_ctx[S.field][q][lane];
 				const uint32_t cj = ci < 1024u ? ci : 0u;
-				uint32_t s = cabac_state_init(r.slice_qp,
-							      mn[8u * cj + 2u * col],
-							      mn[8u * cj + 2u * col + 1u]);
+				uint32_t s = cabac_state_init_q(iq,
+							mn[8u * cj + 2u * col],
+							mn[8u * cj + 2u * col + 1u]);
 				/* pStateIdx | !valMPS << 6 (cs_dec) */
 				s = (s & 63u) | (((s >> 8) ^ 1u) << 6);
 				/* (cabac_init_idc > 2: all states 0, valMPS 0) */

@@ -597,10 +597,19 @@ h264_amd_k_write_slices(sw_args a)
 
 /* 9.3.1.1 with the reference's clipping (ref src/h264_bac.c:216-230):
  * returns pStateIdx | valMPS << 8 */
+__device__ __forceinline__ uint32_t cabac_state_init_q(int32_t qp, int32_t m,
+						       int32_t n);
+
 __device__ __forceinline__ uint32_t cabac_state_init(int32_t qp, int32_t m,
 						     int32_t n)
 {
-	qp = qp < 1 ? 1 : qp > 51 ? 51 : qp;
+	return cabac_state_init_q(qp < 1 ? 1 : qp > 51 ? 51 : qp, m, n);
+}
+
+/* the same with the QP already clipped by the caller */
+__device__ __forceinline__ uint32_t cabac_state_init_q(int32_t qp, int32_t m,
+						       int32_t n)
+{
 	int32_t idx = ((m * qp) >> 4) + n;
 	if (idx <= 63)
 		return (uint32_t)(63 - (idx > 1 ? idx : 1));

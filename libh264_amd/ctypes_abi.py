@@ -362,5 +362,6 @@ TIER_NONE, TIER_T0, TIER_T1, TIER_T2 = 0, 1, 2, 3
 READER_FLAGS_SLICE_DATA = 1
 READER_FLAGS_CABAC = 0x100
 READER_FLAGS_CABAC_X264_PRE151 = 0x200  # engine extension, see h264_amd.h
+READER_FLAGS_CABAC_STD_QP = 0x400  # engine extension, see h264_amd.h
 READER_FLAGS_CABAC_SUBSET = READER_FLAGS_CABAC  # round-2 name
 SR_HEADER_OK, SR_DATA_PARSED, SR_CABAC = 1, 2, 4

@@ -347,7 +347,11 @@ void orc_cabac_init_states(int slice_type, uint32_t cabac_init_idc,
 /* engine extension (no reference behaviour, spec-only, parity unpinned beyond
  * what the reference's writers emit): CABAC slice data, orc_cabac_dec.c */
 int orc_cabac_slice_data(struct h264_bitstream *bs, struct orc_reader *rd);
+void orc_cabac_init_states_floor(int slice_type, uint32_t cabac_init_idc,
+				 int32_t SliceQPLuma, int32_t qp_floor,
+				 uint8_t states[1024][2]);
 extern uint64_t orc_stat_cabac_bins; /* bins decoded (bench statistics) */
+
 extern int orc_quirk_x264_444_cbf; /* decode 4:4:4 streams of x264 < build 151 (test only) */
 extern uint64_t orc_stat_cabac_hist[1026]; /* by ctxIdx; 1024 bypass, 1025 terminate */
 int orc_write_grey_i_slice(struct h264_bitstream *bs, struct orc_ctx *ctx,

@@ -72,11 +72,14 @@ struct cabac {
 	struct bac_state st[1024];
 };
 
-/* ref src/h264_bac.c:216-230 (qp clipped to 1..51, not 0..51) */
-static void state_init(struct bac_state *s, int32_t qp, int8_t m, int8_t n)
+/* ref src/h264_bac.c:216-230 (qp clipped to 1..51, not 0..51: qp_floor 1;
+ * the standard's 9.3.1.1 is qp_floor 0, which only the CABAC decoder -- an
+ * extension -- can be asked for) */
+static void state_init(struct bac_state *s, int32_t qp, int32_t qp_floor,
+		       int8_t m, int8_t n)
 {
 	int32_t idx;
-	qp = qp < 1 ? 1 : qp > 51 ? 51 : qp;
+	qp = qp < qp_floor ? qp_floor : qp > 51 ? 51 : qp;
 	idx = ((m * qp) >> 4) + n;
 	if (idx <= 63) {
 		s->idx = 63 - (idx > 1 ? idx : 1);
@@ -92,6 +95,14 @@ static void state_init(struct bac_state *s, int32_t qp, int8_t m, int8_t n)
 void orc_cabac_init_states(int slice_type, uint32_t cabac_init_idc,
 			   int32_t SliceQPLuma, uint8_t states[1024][2])
 {
+	orc_cabac_init_states_floor(slice_type, cabac_init_idc, SliceQPLuma, 1,
+				    states);
+}
+
+void orc_cabac_init_states_floor(int slice_type, uint32_t cabac_init_idc,
+				 int32_t SliceQPLuma, int32_t qp_floor,
+				 uint8_t states[1024][2])
+{
 	uint32_t col, i;
 	cabac_tables_init();
 	memset(states, 0, 2048);
@@ -103,7 +114,8 @@ void orc_cabac_init_states(int slice_type, uint32_t cabac_init_idc,
 		return;
 	for (i = 0; i < 1024; i++) {
 		struct bac_state s;
-		state_init(&s, SliceQPLuma, s_mn[i][col][0], s_mn[i][col][1]);
+		state_init(&s, SliceQPLuma, qp_floor, s_mn[i][col][0],
+			   s_mn[i][col][1]);
 		states[i][0] = s.idx;
 		states[i][1] = s.mps;
 	}

@@ -23,7 +23,10 @@
  *     the reference's shortcuts -- mb_qp_delta ctxIdxInc 0, transBlock
  *     unavailable -- coincide with the standard on those streams);
  *   * context initialisation is the reference's (orc_cabac_init_states: SliceQPY
- *     clipped to 1..51 where the standard says 0..51);
+ *     clipped to 1..51 where the standard says 0..51), so that the library's
+ *     own writers round-trip at SliceQPY 0; a reader flag switches to
+ *     the standard's clip for streams of other encoders (x264 lossless sits at
+ *     QP 0), the engine's H264_AMD_READER_FLAGS_CABAC_STD_QP;
  *   * an independent ENCODER for the whole macroblock layer written from the
  *     standard (libh264_amd/csrc/gen/h264gen_cabac.inc), whose recorded
  *     macroblock syntax must equal what this decoder reads back.
@@ -1119,8 +1122,10 @@ int orc_cabac_slice_data(struct h264_bitstream *bs, struct orc_reader *rd)
 	c->ctx = ctx;
 	c->field = sh->field_pic_flag ? 1 : 0;
 	c->cat = ctx->sps_derived.ChromaArrayType;
-	orc_cabac_init_states((int)type, sh->cabac_init_idc, ctx->derived.SliceQPLuma,
-			      init);
+	orc_cabac_init_states_floor((int)type, sh->cabac_init_idc,
+				    ctx->derived.SliceQPLuma,
+				    (rd->flags & H264_AMD_READER_FLAGS_CABAC_STD_QP) ? 0 : 1,
+				    init);
 	for (i = 0; i < 1024; i++) {
 		c->st[i].idx = init[i][0];
 		c->st[i].mps = init[i][1];

@@ -23,16 +23,20 @@ def cabac_cfg(**kw):
 
 def cabac_slice(cfg, seed, st, first=0, n=None, **kw):
     kw.setdefault("cabac_init_idc", seed % 3)
-    return streams.rich_slice(cfg, seed, st, first, n, cabac_syntax=1, **kw)
+    kw.setdefault("cabac_syntax", 1)
+    return streams.rich_slice(cfg, seed, st, first, n, **kw)
 
 
-def roundtrip(cfg, slices):
+STD_QP = 0x400   # H264_AMD_READER_FLAGS_CABAC_STD_QP
+
+
+def roundtrip(cfg, slices, flags=FLAGS):
     nals, expects = [], []
     for s in slices:
         nal, exp = gen.slice_nal(cfg, s, want_t2=True)
         nals.append(nal)
         expects.append(exp)
-    rec = orc.parse_nalus([gen.sps(cfg), gen.pps(cfg)] + nals, flags=FLAGS)
+    rec = orc.parse_nalus([gen.sps(cfg), gen.pps(cfg)] + nals, flags=flags)
     for i, (s, exp) in enumerate(zip(slices, expects)):
         r = rec.results[i]
         assert (r.status, r.mb_count) == (0, s.num_mbs), (i, r.status)
@@ -88,6 +92,30 @@ def test_partial_slices_sizes_qp():
                                     (2, 0, 1, 3, 4)[(seed + k) % 5], first, n,
                                     slice_qp_delta=(seed % 52) - 26)
                         for k in range(3)])
+
+
+def qp0_slices(cfg, syntax):
+    return [cabac_slice(cfg, 700 + k, (2, 0, 1)[k % 3], slice_qp_delta=-26,
+                        cabac_syntax=syntax) for k in range(9)]
+
+
+def test_slice_qp_0_context_init_of_the_standard():
+    """9.3.1.1 clips SliceQPY to 0..51, the reference's encoder to 1..51
+    (src/h264_bac.c:216-230): a slice at SliceQPY 0 decodes with the clip its
+    encoder used (H264_AMD_READER_FLAGS_CABAC_STD_QP for the standard's), and
+    is lost with the other one."""
+    cfg = cabac_cfg(cf=1)
+    roundtrip(cfg, qp0_slices(cfg, 1))
+    roundtrip(cfg, qp0_slices(cfg, 2), flags=FLAGS | STD_QP)
+    for syntax, flags in ((2, FLAGS), (1, FLAGS | STD_QP)):
+        with pytest.raises(AssertionError):
+            roundtrip(cfg, qp0_slices(cfg, syntax), flags=flags)
+    # above QP 0 the flag changes nothing
+    cfg = cabac_cfg(cf=3)
+    s = [cabac_slice(cfg, 720 + k, (2, 0, 1)[k % 3], slice_qp_delta=-25 + k,
+                     cabac_syntax=1 + k % 2) for k in range(6)]
+    roundtrip(cfg, s)
+    roundtrip(cfg, s, flags=FLAGS | STD_QP)
 
 
 def test_without_the_flag_nothing_is_walked():

@@ -15,23 +15,24 @@ import streams
 from libh264_amd import gen
 from libh264_amd.ctypes_abi import (TIER_NONE, TIER_T0, TIER_T1, TIER_T2,
                                     t2_stride)
-from test_cabac_full import FLAGS, cabac_cfg, cabac_slice
+from test_cabac_full import FLAGS, STD_QP, cabac_cfg, cabac_slice, qp0_slices
 from test_gpu_cabac import compare
 
 pytestmark = pytest.mark.gpu
 
 
-def run(engine, cfg, slices, tier=TIER_T2, lead=0, expect=True):
+def run(engine, cfg, slices, tier=TIER_T2, lead=0, expect=True, flags=FLAGS):
     head = [gen.sps(cfg), gen.pps(cfg)]
     nals, exps = [], []
     for s in slices:
         nal, exp = gen.slice_nal(cfg, s, want_t2=True)
         nals.append(nal)
         exps.append(exp)
-    ref, res = compare(engine, head, nals, tier=tier, lead=lead)
+    ref, res = compare(engine, head, nals, tier=tier, lead=lead, flags=flags)
     for i, s in enumerate(slices):
-        assert (res[i].status, res[i].mb_count, res[i].flags) == \
-            (0, s.num_mbs, 7), i
+        if expect is not None:
+            assert (res[i].status, res[i].mb_count, res[i].flags) == \
+                (0, s.num_mbs, 7), i
         if expect:   # the oracle agrees with the encoder (CPU test): so must we
             assert np.array_equal(ref.mb_records(i), exps[i]), i
     return ref, res, nals
@@ -85,6 +86,19 @@ def test_partial_slices_sizes_qp(engine):
                                       (2, 0, 1, 3, 4)[(seed + k) % 5], first,
                                       n, slice_qp_delta=(seed % 52) - 26)
                           for k in range(3)], lead=seed % 4)
+
+
+def test_slice_qp_0_context_init_of_the_standard(engine):
+    """H264_AMD_READER_FLAGS_CABAC_STD_QP: both clips of SliceQPY on slices of
+    both kinds of encoder -- the matching pairs decode, the crossed pairs are
+    damaged input on which kernel and oracle must still agree."""
+    for cf in (1, 3):
+        cfg = cabac_cfg(cf=cf)
+        for syntax in (1, 2):
+            for flags in (FLAGS, FLAGS | STD_QP):
+                match = (syntax == 2) == bool(flags & STD_QP)
+                run(engine, cfg, qp0_slices(cfg, syntax), flags=flags,
+                    expect=True if match else None)
 
 
 def test_1080p_slices(engine):
