@@ -2,7 +2,8 @@
 """Volume fuzz of the CABAC slice-data kernel (h264_amd_k_decode_cabac) against
 the oracle's decoder on REAL content: slices from the generator's own arithmetic
 encoder -- I / SI / P / SP / B, four chroma formats, bit depths, 8x8 transform,
-I_PCM, field pictures, partial slices, every cabac_init_idc, the QP range, wide
+I_PCM, field pictures, partial slices, every cabac_init_idc, the QP range
+(below 0 too, with either clip of the context initialisation), wide
 and narrow pictures -- two in three of them then damaged (bit flips, truncation,
 spliced tails, padding).  Status, macroblocks delivered before an error, header
 images and records in a random tier must be equal.  Machinery of
@@ -22,13 +23,17 @@ import libh264_amd  # noqa: E402
 import streams  # noqa: E402
 from libh264_amd import gen  # noqa: E402
 from libh264_amd.ctypes_abi import TIER_T2, TIER_T1, TIER_T0, TIER_NONE  # noqa: E402
-from test_cabac_full import cabac_cfg, cabac_slice  # noqa: E402
+from test_cabac_full import FLAGS, STD_QP, cabac_cfg, cabac_slice  # noqa: E402
 from test_gpu_cabac import compare  # noqa: E402
 from test_gpu_fuzz import mutate  # noqa: E402
 
 
 def one(engine, seed):
     rnd = random.Random(seed)
+    # either QP clip of the context initialisation, in the slices and in the
+    # decoders (a stream of its own: earlier seeds keep their slices)
+    rq = random.Random(seed ^ 0x51c0)
+    flags = FLAGS | (STD_QP if rq.randrange(2) else 0)
     cf = rnd.choice([1, 1, 1, 2, 0, 3])
     bd = rnd.choice([0, 0, 2, 4]) if cf != 1 else rnd.choice([0, 0, 0, 2])
     width = rnd.choice([1, 2, 3, 5, 8, 11, 20, 45])
@@ -57,7 +62,8 @@ def one(engine, seed):
                         pm_t8x8=rnd.choice([0, 400, 900]),
                         pm_skip=rnd.choice([0, 200, 700]),
                         pm_cbp_zero=rnd.choice([0, 100, 600]),
-                        field_pic=rnd.randrange(3) if fc else 0)
+                        field_pic=rnd.randrange(3) if fc else 0,
+                        cabac_syntax=rq.choice([1, 1, 2]))
         try:
             nal = gen.slice_nal(cfg, s)
         except OSError:
@@ -78,7 +84,8 @@ def one(engine, seed):
     tier = rnd.choice([TIER_T2, TIER_T2, TIER_T1, TIER_T0, TIER_NONE])
     try:
         compare(engine, head, nals, tier=tier,
-                cap=rnd.choice([total + 2, total + 2, 7]), lead=seed % 4)
+                cap=rnd.choice([total + 2, total + 2, 7]), lead=seed % 4,
+                flags=flags)
     except AssertionError as e:
         return "seed %d (w %d h %d cf %d bd %d fc %d): %s" % (
             seed, width, height, cf, bd, fc, str(e)[:int(os.environ.get("FUZZ_MSG", "300"))])
