@@ -1048,12 +1048,12 @@ sd_residual_block(VBits &vb, WaveBits &wb, const VlcTabs &vt, uint32_t lane,
 				VB_VREG(code);
 				codes = lane == i ? code : codes;
 			} else {
-				/* prefix zeros, a one, sl0 suffix bits: the n bits of
-				 * the code word end in "1 suffix" = 2^sl0 + suffix, and
-				 * levelCode = (prefix << sl0) + suffix
-				 *           = ((prefix - 1) << sl0) + that */
+				/* prefix zeros, a one, sl0 suffix bits (the low sl0 of
+				 * the code word's n):
+				 * levelCode = (prefix << sl0) + suffix */
 				uint32_t n = p + 1u + sl0;
-				uint32_t code = ((p - 1u) << sl0) + (b1 >> (32u - n)) +
+				uint32_t code = (p << sl0) +
+						__builtin_amdgcn_ubfe(b1, 32u - n, sl0) +
 						first_adj;
 				vb_skip(vb, n); /* <= 16 bits */
 				/* suffixLength becomes 1, and 2 when the magnitude
@@ -1075,18 +1075,32 @@ sd_residual_block(VBits &vb, WaveBits &wb, const VlcTabs &vt, uint32_t lane,
 		 * scalar side (one s_lshl_b64 per level) instead of a v_cmp into
 		 * VCC with its wait states before the select */
 		uint64_t imask = 1ull << i;
-		for (; i < tc; i++, imask <<= 1) {
+		const uint64_t iend = 1ull << tc; /* tc <= 16 */
+		for (; imask != iend; imask <<= 1) {
 			/* (raw peek: the test below is a 32-bit one already) */
 			uint32_t b1 = (uint32_t)((vb.W << vb.vo) >> 32);
-			uint32_t p = (uint32_t)__builtin_clz(b1 | 0x10000u);
+			/* (as asm: the optimiser reads "p >= 3" below through a
+			 * count of leading zeros as a 64-bit compare of the
+			 * shifted window with a constant, for which the kernel
+			 * has no scalar registers left) */
+			uint32_t p;
+			asm("v_ffbh_u32 %0, %1" : "=v"(p) : "v"(b1 | 0x10000u));
 			uint32_t n = p + 1u + sl;
-			/* p >= 15  <=>  p + 29 >= 44;  vo >= 44 behind the level:
-			 * step.  The cursor moves first and an escape takes it
-			 * back: no copy of the old offset is carried. */
+			/* vo >= 44 behind the level: step.  p >= 15: vo is 17 at
+			 * least and vo + 2 p >= 44 as well; a smaller p that
+			 * trips the test early (vo >= 38) takes the step path a
+			 * level before it must, which that path does not mind.
+			 * The cursor moves first and an escape takes it back: no
+			 * copy of the old offset is carried. */
 			vb.vo += n; /* n <= 21 bits */
-			const uint32_t p29 = p + 29u;
-			uint32_t rare = p29 > vb.vo ? p29 : vb.vo;
+			const uint32_t rare = vb.vo + 2u * p;
 			if (vb_true(rare >= 44u)) {
+				const uint32_t i = (uint32_t)__builtin_ctzll(imask);
+				/* (opaque here, so that the sum above is made in
+				 * place: otherwise the old offset stays live for
+				 * the subtraction below and every level pays a
+				 * register copy) */
+				VB_VREG(vb.vo);
 				if (vb_true(p >= 15u)) {
 					uint32_t ssl = (uint32_t)
 						__builtin_amdgcn_readfirstlane((int)sl);
@@ -1109,18 +1123,20 @@ sd_residual_block(VBits &vb, WaveBits &wb, const VlcTabs &vt, uint32_t lane,
 				}
 				continue;
 			}
-			uint32_t code = ((p - 1u) << sl) + (b1 >> (32u - n));
+			uint32_t code = (p << sl) + __builtin_amdgcn_ubfe(b1, 32u - n, sl);
+			uint32_t grown = sl + (p >= 3u ? 1u : 0u);
+			sl = grown < 6u ? grown : 6u;
 			asm("v_cndmask_b32 %0, %0, %1, %2"
 			    : "+v"(codes)
 			    : "v"(code), "s"(imask));
-			/* + 1 iff p >= 3, without a compare: p + 29 is 29 .. 31
-			 * for p < 3 and 32 .. 43 up to p = 14 */
-			uint32_t grown = sl + (p29 >> 4) - 1u;
-			sl = grown < 6u ? grown : 6u;
 		}
+		i = tc;
 	}
 	SD_T(5);
-	/* ---- total_zeros and the runs: zl = zerosLeft before run i, per lane ---- */
+	/* ---- total_zeros and the runs: zl = zerosLeft before run i, per lane
+	 * (collecting them as nibbles of a scalar pair, two scalar operations a
+	 * run instead of three vector ones, is slower at four waves a SIMD: the
+	 * scalar unit is the fuller one there, profiles/r03_decode_ab_history) ---- */
 	uint32_t zl = 0;
 	uint32_t zeros_left = 0;
 	if (tc < maxnum) {
@@ -1141,7 +1157,7 @@ sd_residual_block(VBits &vb, WaveBits &wb, const VlcTabs &vt, uint32_t lane,
 	 * 6) or a unary tail (0001 -> 7, ...), up to 11 bits, one at a time.
 	 * zerosLeft <= 6: at most 3 bits, so ten of them fit behind one vb_norm();
 	 * a byte table per class held by lane `class` (vt.rb_lo / rb_hi), entry =
-	 * len << 4 | run picked by the next three bits. */
+	 * len << 4 | zerosLeft behind the run, picked by the next three bits. */
 	SD_T(6);
 	i = 0;
 	/* (loop conditions as ONE compare of a minimum: "runs still to read and
@@ -1174,13 +1190,15 @@ sd_residual_block(VBits &vb, WaveBits &wb, const VlcTabs &vt, uint32_t lane,
 		do {
 			zl = wb_setlane(zl, i, zeros_left, lane);
 			uint32_t top3 = vb_peek(vb) >> 29;
-			/* byte top3 of the lane's eight (selector 0x0c: zero) */
-			uint32_t ev = __builtin_amdgcn_perm(vt.rb_hi, vt.rb_lo,
-							    top3 | 0x0c0c0c00u);
+			/* byte top3 of the lane's eight in byte 0 (the other
+			 * three selectors are 0: copies of the lane's first
+			 * byte, masked off below -- cheaper than making them
+			 * zero selectors first) */
+			uint32_t ev = __builtin_amdgcn_perm(vt.rb_hi, vt.rb_lo, top3);
 			uint32_t e = (uint32_t)__builtin_amdgcn_readlane(
 				(int)ev, (int)zeros_left);
-			vb_skip(vb, e >> 4); /* <= 3 bits */
-			zeros_left -= e & 15u;
+			vb_skip(vb, (e >> 4) & 15u); /* <= 3 bits */
+			zeros_left = e & 15u; /* the table has zerosLeft - run */
 			i++;
 			batch--;
 		} while ((batch < zeros_left ? batch : zeros_left) != 0u);
@@ -2120,7 +2138,17 @@ sd_slice_data(WaveBits &wb, const VlcTabs &vt, uint32_t cbp_map, uint32_t lane,
 					 * lane (scalar side: the vector port is the
 					 * fuller one); chroma DC blocks have their own */
 					uint32_t cls = vlc_ct_class(sd_nc(m, info >> 24));
-					cls = ((info >> 11) & 3u) ? 3u + cat : cls;
+					{
+						/* cls = ((info >> 11) & 3) ? 3 + cat : cls,
+						 * on the condition code of the s_and (the
+						 * backend adds a compare) */
+						uint32_t dc = 3u + cat, t;
+						asm("s_and_b32 %1, %2, 0x1800\n\t"
+						    "s_cselect_b32 %0, %3, %0"
+						    : "+s"(cls), "=&s"(t)
+						    : "s"(info), "s"(dc)
+						    : "scc");
+					}
 					SD_T(11);
 					uint32_t tc = sd_residual_block(
 						vb, wb, vt, lane, stage, cls, peek,

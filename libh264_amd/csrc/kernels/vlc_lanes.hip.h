@@ -57,18 +57,18 @@ __device__ __forceinline__ void vlc_open(VlcTabs &t, const uint8_t *lds_tabs,
 	t.tz = lds_tabs + DEV_VLC_CT_CLASSES * 64u * 8u;
 	t.off64 = 8u * lane;
 	t.off16 = 8u * (lane & 15u);
-	/* run_before, zerosLeft 1..6: entry = len << 4 | run for each value of
-	 * the next 3 bits, 8 entries packed into the 64-bit word of lane
-	 * zerosLeft (Table 9-10):
+	/* run_before, zerosLeft 1..6: entry = len << 4 | (zerosLeft - run), i.e.
+	 * what is left behind the run, for each value of the next 3 bits, 8
+	 * entries packed into the 64-bit word of lane zerosLeft (Table 9-10):
 	 *  1: 1 0            2: 1 01 00          3: 11 10 01 00
 	 *  4: 11 10 01 001 000                   5: 11 10 011 010 001 000
 	 *  6: 11 000 001 011 010 101 100 (runs 0..6) */
-	uint64_t tb = lane == 1   ? 0x1010101011111111ull
-		      : lane == 2 ? 0x1010101021212222ull
-		      : lane == 3 ? 0x2020212122222323ull
-		      : lane == 4 ? 0x2020212122223334ull
-		      : lane == 5 ? 0x2020212132333435ull
-		      : lane == 6 ? 0x2020353633343231ull
+	uint64_t tb = lane == 1   ? 0x1111111110101010ull
+		      : lane == 2 ? 0x1212121221212020ull
+		      : lane == 3 ? 0x2323222221212020ull
+		      : lane == 4 ? 0x2424232322223130ull
+		      : lane == 5 ? 0x2525242433323130ull
+		      : lane == 6 ? 0x2626313033323435ull
 				  : 0ull;
 	t.rb_lo = (uint32_t)tb;
 	t.rb_hi = (uint32_t)(tb >> 32);
@@ -103,12 +103,17 @@ __device__ __forceinline__ uint32_t vlc_match_total(const uint8_t *row,
 	return (uint32_t)__builtin_amdgcn_readlane((int)e.y, __builtin_ctzll(m));
 }
 
-/* class of coeff_token table for nC = 0..8+: 0 0 1 1 2 2 2 2 3, two bits each
- * (works on scalars and per lane alike) */
+/* class of coeff_token table for a wave-uniform nC = 0..8+: 0 0 1 1 2 2 2 2 3,
+ * two bits each of 0x3AA50, as a scalar bit field extract with the operand
+ * 2 c | 2 << 16 (three scalar operations; shift, shift and mask are four) */
 __device__ __forceinline__ uint32_t vlc_ct_class(uint32_t nC)
 {
 	uint32_t c = nC < 8u ? nC : 8u;
-	return (0x3AA50u >> (2u * c)) & 3u;
+	uint32_t cls;
+	asm("s_lshl1_add_u32 %0, %1, 0x20000\n\ts_bfe_u32 %0, 0x3aa50, %0"
+	    : "=&s"(cls)
+	    : "s"(c));
+	return cls;
 }
 
 /* total_zeros; maxnum selects the table family (4: chroma DC 2x2, 8: chroma
@@ -159,7 +164,7 @@ __device__ __forceinline__ uint32_t vlc_run_before(const VlcTabs &t, WaveBits &s
 							  (int)zeros_left);
 	uint32_t e = (uint32_t)(tb >> (8u * top3)) & 0xffu;
 	wb_skip(s, e >> 4);
-	run = e & 15u;
+	run = zeros_left - (e & 15u);
 	return 0;
 }
 
