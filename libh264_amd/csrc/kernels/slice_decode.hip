@@ -1009,7 +1009,7 @@ sd_residual_block(VBits &vb, WaveBits &wb, const VlcTabs &vt, uint32_t lane,
 	}
 	vb_skip(vb, len); /* <= 16 bits */
 	SD_T(4);
-	if (tc == 0)
+	if (__builtin_expect(tc == 0, 0))
 		return 0;
 	/* ---- trailing ones: bit (t1 - 1 - i) of the sign field is level i, i.e.
 	 * bit 31 - i of what the peek holds behind the token (at most 16 bits
@@ -1037,7 +1037,7 @@ sd_residual_block(VBits &vb, WaveBits &wb, const VlcTabs &vt, uint32_t lane,
 			uint32_t b1 = vb_peek(vb);
 			/* 15 stands for "15 or more": the escape path looks again */
 			uint32_t p = (uint32_t)__builtin_clz(b1 | 0x10000u);
-			if (vb_true(p >= 14u + sl0)) {
+			if (__builtin_expect(vb_true(p >= 14u + sl0), 0)) {
 				uint32_t ssl = sl0;
 				vb_store(vb, wb);
 				uint32_t code = sd_level_escape(wb, lane, ssl, first_adj,
@@ -1094,7 +1094,7 @@ sd_residual_block(VBits &vb, WaveBits &wb, const VlcTabs &vt, uint32_t lane,
 			 * copy of the old offset is carried. */
 			vb.vo += n; /* n <= 21 bits */
 			const uint32_t rare = vb.vo + 2u * p;
-			if (vb_true(rare >= 44u)) {
+			if (__builtin_expect(vb_true(rare >= 44u), 0)) {
 				const uint32_t i = (uint32_t)__builtin_ctzll(imask);
 				/* (opaque here, so that the sum above is made in
 				 * place: otherwise the old offset stays live for
@@ -1482,7 +1482,7 @@ __device__ __forceinline__ void sd_next_mb_mbaff(MbCtx &m, PairCtx &P, uint8_t *
 __device__ __forceinline__ void sd_vb_sync(VBits &b, WaveBits &s, uint32_t lane,
 					   const SliceState &S)
 {
-	if (b.sd >= WB_SLIDE_BITS / 32u) {
+	if (__builtin_expect(b.sd >= WB_SLIDE_BITS / 32u, 0)) {
 		vb_store(b, s);
 		wb_sync(s, lane);
 		vb_load(b, s);
@@ -1530,13 +1530,13 @@ sd_slice_data(WaveBits &wb, const VlcTabs &vt, uint32_t cbp_map, uint32_t lane,
 #define VRD_UE(var)                                                            \
 	do {                                                                   \
 		var = vb_ue(vb, wb, ok);                                       \
-		if (!ok)                                                       \
+		if (__builtin_expect(!ok, 0))                                  \
 			return -EIO;                                           \
 	} while (0)
 #define VRD_SE(var)                                                            \
 	do {                                                                   \
 		var = vb_se(vb, wb, ok);                                       \
-		if (!ok)                                                       \
+		if (__builtin_expect(!ok, 0))                                  \
 			return -EIO;                                           \
 	} while (0)
 	MbCtx m;
@@ -1689,7 +1689,7 @@ sd_slice_data(WaveBits &wb, const VlcTabs &vt, uint32_t cbp_map, uint32_t lane,
 		/* the scalar cursor is in step with vb here (vb_store at the end of
 		 * the previous macroblock / vb_load above) */
 		sd_vb_sync(vb, wb, lane, S);
-		if (wb_overrun(wb))
+		if (__builtin_expect(wb_overrun(wb), 0))
 			return -EIO;
 		if (!is_i) {
 			uint32_t run;
@@ -2159,12 +2159,12 @@ sd_slice_data(WaveBits &wb, const VlcTabs &vt, uint32_t cbp_map, uint32_t lane,
 					sd_nz_set(m, nzlane, tc, lane);
 					SD_T(12);
 				}
-				if (serr)
+				if (__builtin_expect(serr != 0, 0))
 					return -EIO;
 			}
 		}
 		vb_store(vb, wb);
-		if (wb_overrun(wb))
+		if (__builtin_expect(wb_overrun(wb), 0))
 			return -EIO;
 		SD_T(13);
 

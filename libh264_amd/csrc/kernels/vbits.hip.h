@@ -75,7 +75,10 @@ __device__ __forceinline__ void vb_store(const VBits &b, WaveBits &s)
 /* vo < 64 on entry */
 __device__ __forceinline__ void vb_norm(VBits &b, const WaveBits &s)
 {
-	if (vb_true(b.vo >= 32u)) {
+	/* one time in three or four; said to be unlikely so that the refill sits
+	 * out of line and the usual way is the branch not taken (19 cycles of a
+	 * lone wave against 31-34 taken) */
+	if (__builtin_expect(vb_true(b.vo >= 32u), 0)) {
 		b.sd += 1u;
 		uint32_t nx = (uint32_t)__builtin_amdgcn_readlane((int)s.wnext,
 								  (int)b.sd);
@@ -88,7 +91,7 @@ __device__ __forceinline__ void vb_norm(VBits &b, const WaveBits &s)
 /* the window slide of wb_sync() for a cursor kept here */
 __device__ __forceinline__ void vb_sync(VBits &b, WaveBits &s, uint32_t lane)
 {
-	if (b.sd >= WB_SLIDE_BITS / 32u) {
+	if (__builtin_expect(b.sd >= WB_SLIDE_BITS / 32u, 0)) {
 		vb_store(b, s);
 		wb_sync(s, lane);
 		vb_load(b, s);
@@ -139,7 +142,9 @@ __device__ __forceinline__ uint32_t vb_ue(VBits &b, const WaveBits &s, bool &ok)
 {
 	vb_norm(b, s);
 	uint32_t v = vb_peek_s(b);
-	if (v >= 0x10000u) {
+	/* (the usual way falls through: a branch not taken is 12-15 cycles
+	 * cheaper for a wave alone on its SIMD than one taken) */
+	if (__builtin_expect(v >= 0x10000u, 1)) {
 		uint32_t lz = (uint32_t)__builtin_clz(v);
 		vb_skip(b, 2u * lz + 1u);
 		return (v >> (31u - 2u * lz)) - 1u;
