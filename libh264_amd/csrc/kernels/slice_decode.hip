@@ -99,6 +99,12 @@ struct SliceState {
  * dump slot in LDS (or repeat a neighbour's identical store). */
 #define SD_DUMP_BYTES 1024u /* 64 lanes x 16 B */
 
+/* a condition that is rarely true: its code goes out of line and the usual way
+ * is the branch not taken -- 19 cycles of a wave alone on its SIMD against
+ * 31-34 for one taken (profiles/r02_decode_cost_model.md) */
+#define SD_RARE(c) __builtin_expect(!!(c), 0)
+#define SD_USUAL(c) __builtin_expect(!!(c), 1)
+
 __device__ __forceinline__ uint8_t *lds_sel(uint8_t *real, uint8_t *dump,
 					    bool take, uint32_t lane)
 {
@@ -180,7 +186,7 @@ __device__ __forceinline__ int sd_rplm_items(WaveBits &wb, uint32_t lane,
 	bool ok = true;
 	uint32_t i = 0, val;
 	do {
-		if (i >= 32)
+		if (SD_RARE(i >= 32))
 			return -EIO;
 		wb_sync(wb, lane);
 		RD_UE(val);
@@ -252,20 +258,20 @@ sd_slice_header(WaveBits &wb, uint32_t lane, uint8_t *stage, SliceState &S,
 	/* a ue that ran past the end of the NAL is the reference's -EIO on the
 	 * read itself, before it looks at the value (found by the drop-in fuzz:
 	 * the zero padding made pps_id large and -EINVAL won) */
-	if (wb_overrun(wb))
+	if (SD_RARE(wb_overrun(wb)))
 		return -EIO;
 	/* h264_ctx_set_active_pps -> set_active_sps (src/h264_ctx.c:366-386) */
-	if (pps_id >= 256)
+	if (SD_RARE(pps_id >= 256))
 		return -EINVAL;
 	uint32_t pv = wb_uniform(ep->pps_ver[pps_id]);
-	if (pv == DEV_NO_VERSION || pv >= n_pps)
+	if (SD_RARE(pv == DEV_NO_VERSION || pv >= n_pps))
 		return -EINVAL;
 	dev_pps pps;
 	sd_load_uniform(&pps, ppsv + pv);
-	if (pps.seq_parameter_set_id >= 32)
+	if (SD_RARE(pps.seq_parameter_set_id >= 32))
 		return -EINVAL;
 	uint32_t sver = wb_uniform(ep->sps_ver[pps.seq_parameter_set_id]);
-	if (sver == DEV_NO_VERSION || sver >= n_sps)
+	if (SD_RARE(sver == DEV_NO_VERSION || sver >= n_sps))
 		return -EINVAL;
 	dev_sps sps;
 	sd_load_uniform(&sps, spsv + sver);
@@ -291,7 +297,7 @@ sd_slice_header(WaveBits &wb, uint32_t lane, uint8_t *stage, SliceState &S,
 		HP(colour_plane_id, v);
 	}
 	v = wb_u_any(wb, lane, sps.log2_max_frame_num, ok);
-	if (!ok)
+	if (SD_RARE(!ok))
 		return -EIO;
 	HP(frame_num, v);
 	if (!sps.frame_mbs_only_flag) {
@@ -309,7 +315,7 @@ sd_slice_header(WaveBits &wb, uint32_t lane, uint8_t *stage, SliceState &S,
 	wb_sync(wb, lane);
 	if (sps.pic_order_cnt_type == 0) {
 		v = wb_u_any(wb, lane, sps.log2_max_pic_order_cnt_lsb, ok);
-		if (!ok)
+		if (SD_RARE(!ok))
 			return -EIO;
 		HP(pic_order_cnt_lsb, v);
 		if (pps.bottom_field_pic_order_in_frame_present_flag && !field_pic) {
@@ -380,13 +386,13 @@ sd_slice_header(WaveBits &wb, uint32_t lane, uint8_t *stage, SliceState &S,
 			RD_UE(v);
 			HP(pwt.chroma_log2_weight_denom, v);
 		}
-		if (nref0 > 32)
+		if (SD_RARE(nref0 > 32))
 			return -EIO;
 		int r = sd_pwt_list(wb, lane, stage, HOFF(pwt.l0), nref0 + 1, pcat);
 		if (r)
 			return r;
 		if (type == H264_SLICE_TYPE_B) {
-			if (nref1 > 32)
+			if (SD_RARE(nref1 > 32))
 				return -EIO;
 			r = sd_pwt_list(wb, lane, stage, HOFF(pwt.l1), nref1 + 1,
 					pcat);
@@ -409,7 +415,7 @@ sd_slice_header(WaveBits &wb, uint32_t lane, uint8_t *stage, SliceState &S,
 				uint32_t i = 0, op;
 				do {
 					uint32_t o = HOFF(drpm.mm) + 20 * i;
-					if (i >= 64)
+					if (SD_RARE(i >= 64))
 						return -EIO;
 					wb_sync(wb, lane);
 					RD_UE(op);
@@ -1009,7 +1015,7 @@ sd_residual_block(VBits &vb, WaveBits &wb, const VlcTabs &vt, uint32_t lane,
 	}
 	vb_skip(vb, len); /* <= 16 bits */
 	SD_T(4);
-	if (__builtin_expect(tc == 0, 0))
+	if (SD_RARE(tc == 0))
 		return 0;
 	/* ---- trailing ones: bit (t1 - 1 - i) of the sign field is level i, i.e.
 	 * bit 31 - i of what the peek holds behind the token (at most 16 bits
@@ -1037,7 +1043,7 @@ sd_residual_block(VBits &vb, WaveBits &wb, const VlcTabs &vt, uint32_t lane,
 			uint32_t b1 = vb_peek(vb);
 			/* 15 stands for "15 or more": the escape path looks again */
 			uint32_t p = (uint32_t)__builtin_clz(b1 | 0x10000u);
-			if (__builtin_expect(vb_true(p >= 14u + sl0), 0)) {
+			if (SD_RARE(vb_true(p >= 14u + sl0))) {
 				uint32_t ssl = sl0;
 				vb_store(vb, wb);
 				uint32_t code = sd_level_escape(wb, lane, ssl, first_adj,
@@ -1094,7 +1100,7 @@ sd_residual_block(VBits &vb, WaveBits &wb, const VlcTabs &vt, uint32_t lane,
 			 * copy of the old offset is carried. */
 			vb.vo += n; /* n <= 21 bits */
 			const uint32_t rare = vb.vo + 2u * p;
-			if (__builtin_expect(vb_true(rare >= 44u), 0)) {
+			if (SD_RARE(vb_true(rare >= 44u))) {
 				const uint32_t i = (uint32_t)__builtin_ctzll(imask);
 				/* (opaque here, so that the sum above is made in
 				 * place: otherwise the old offset stays live for
@@ -1139,7 +1145,7 @@ sd_residual_block(VBits &vb, WaveBits &wb, const VlcTabs &vt, uint32_t lane,
 	 * scalar unit is the fuller one there, profiles/r03_decode_ab_history) ---- */
 	uint32_t zl = 0;
 	uint32_t zeros_left = 0;
-	if (tc < maxnum) {
+	if (SD_USUAL(tc < maxnum)) {
 		vb_norm(vb, wb);
 		uint32_t b1 = vb_peek(vb);
 		/* 1 <= tc < maxnum and maxnum in {4, 8, 15, 16} (the callers' block
@@ -1270,7 +1276,7 @@ __device__ __forceinline__ void sd_t0_put(OutCtx &o, uint32_t word0,
 					  uint32_t mbidx, uint32_t lane)
 {
 	o.t0acc = wb_setlane(o.t0acc, mbidx & 63u, word0, lane);
-	if ((mbidx & 63u) == 63u)
+	if (SD_RARE((mbidx & 63u) == 63u))
 		*reinterpret_cast<uint32_t *>(
 			o.mb_out + (size_t)(mbidx - 63u + lane) * o.mb_stride) = o.t0acc;
 }
@@ -1482,7 +1488,7 @@ __device__ __forceinline__ void sd_next_mb_mbaff(MbCtx &m, PairCtx &P, uint8_t *
 __device__ __forceinline__ void sd_vb_sync(VBits &b, WaveBits &s, uint32_t lane,
 					   const SliceState &S)
 {
-	if (__builtin_expect(b.sd >= WB_SLIDE_BITS / 32u, 0)) {
+	if (SD_RARE(b.sd >= WB_SLIDE_BITS / 32u)) {
 		vb_store(b, s);
 		wb_sync(s, lane);
 		vb_load(b, s);
@@ -1530,13 +1536,13 @@ sd_slice_data(WaveBits &wb, const VlcTabs &vt, uint32_t cbp_map, uint32_t lane,
 #define VRD_UE(var)                                                            \
 	do {                                                                   \
 		var = vb_ue(vb, wb, ok);                                       \
-		if (__builtin_expect(!ok, 0))                                  \
+		if (SD_RARE(!ok))                                  \
 			return -EIO;                                           \
 	} while (0)
 #define VRD_SE(var)                                                            \
 	do {                                                                   \
 		var = vb_se(vb, wb, ok);                                       \
-		if (__builtin_expect(!ok, 0))                                  \
+		if (SD_RARE(!ok))                                  \
 			return -EIO;                                           \
 	} while (0)
 	MbCtx m;
@@ -1689,7 +1695,7 @@ sd_slice_data(WaveBits &wb, const VlcTabs &vt, uint32_t cbp_map, uint32_t lane,
 		/* the scalar cursor is in step with vb here (vb_store at the end of
 		 * the previous macroblock / vb_load above) */
 		sd_vb_sync(vb, wb, lane, S);
-		if (__builtin_expect(wb_overrun(wb), 0))
+		if (SD_RARE(wb_overrun(wb)))
 			return -EIO;
 		if (!is_i) {
 			uint32_t run;
@@ -1698,11 +1704,11 @@ sd_slice_data(WaveBits &wb, const VlcTabs &vt, uint32_t cbp_map, uint32_t lane,
 			 * the reference's -EIO on the ue itself: no skipped
 			 * macroblock may come out of it */
 			vb_store(vb, wb);
-			if (wb_overrun(wb))
+			if (SD_RARE(wb_overrun(wb)))
 				return -EIO;
 			prev_mb_skipped = run > 0;
 			for (uint32_t r = 0; r < run; r++) {
-				if (mbidx >= mb_capacity)
+				if (SD_RARE(mbidx >= mb_capacity))
 					return H264_AMD_E_MB_OVERFLOW;
 				/* under slice groups the address runs ahead of
 				 * the count (h264_amd.h, H264_AMD_MAX_SLICE_MBS) */
@@ -1748,9 +1754,9 @@ sd_slice_data(WaveBits &wb, const VlcTabs &vt, uint32_t cbp_map, uint32_t lane,
 			if (run > 0 && !wb_more_rbsp_data(wb, lane))
 				break;
 		}
-		if (mbidx >= mb_capacity)
+		if (SD_RARE(mbidx >= mb_capacity))
 			return H264_AMD_E_MB_OVERFLOW;
-		if (fmo && cur_addr - first_addr >= H264_AMD_MAX_SLICE_MBS)
+		if (SD_RARE(fmo && cur_addr - first_addr >= H264_AMD_MAX_SLICE_MBS))
 			return H264_AMD_E_MB_OVERFLOW;
 
 		/* ---- new macroblock: neighbours, clean record ---- */
@@ -1859,7 +1865,7 @@ sd_slice_data(WaveBits &wb, const VlcTabs &vt, uint32_t cbp_map, uint32_t lane,
 		if (intra) {
 			/* Table 7-11 from the table the lanes hold (lane = mb_type
 			 * value): no chain of compares */
-			if (t > 25)
+			if (SD_RARE(t > 25))
 				return -EIO;
 			uint32_t e = (uint32_t)__builtin_amdgcn_readlane((int)itab,
 									  (int)t);
@@ -1876,11 +1882,11 @@ sd_slice_data(WaveBits &wb, const VlcTabs &vt, uint32_t cbp_map, uint32_t lane,
 		uint32_t pred_lo = 0, pred_hi = 0; /* pred[8] of the summary */
 		SD_T(1);
 
-		if (mb_type == H264_MB_TYPE_I_PCM) {
+		if (SD_RARE(mb_type == H264_MB_TYPE_I_PCM)) {
 			/* pcm_alignment_zero_bit, then raw samples (:622-645) */
 			vb_store(vb, wb);
 			uint32_t p = wb_pos(wb) & 7u;
-			if (p && wb_u(wb, lane, 8u - p) != 0)
+			if (SD_RARE(p && wb_u(wb, lane, 8u - p) != 0))
 				return -EIO;
 			/* 64 samples per step, one per lane: the sample counts (256
 			 * luma, 0 / 64 / 128 / 256 per chroma plane) are multiples of
@@ -1891,7 +1897,7 @@ sd_slice_data(WaveBits &wb, const VlcTabs &vt, uint32_t cbp_map, uint32_t lane,
 			const uint32_t total = 256u + 2u * S.pcm_chroma;
 			for (uint32_t k0 = 0; k0 < total; k0 += 64u) {
 				wb_sync(wb, lane);
-				if (wb_overrun(wb))
+				if (SD_RARE(wb_overrun(wb)))
 					return -EIO;
 				const uint32_t bd = k0 < 256u ? S.bdl : S.bdc;
 				uint32_t off = wb.bitpos + lane * bd;
@@ -1920,7 +1926,7 @@ sd_slice_data(WaveBits &wb, const VlcTabs &vt, uint32_t cbp_map, uint32_t lane,
 					VRD_UE(st);
 					pred_lo |= (st & 0xffu) << (8u * p);
 					if (is_b) {
-						if (st >= 13)
+						if (SD_RARE(st >= 13))
 							return -EIO;
 						/* Table 7-18 */
 						sub_pm[p] = st == 0   ? (uint32_t)PM_DIRECT
@@ -1932,7 +1938,7 @@ sd_slice_data(WaveBits &wb, const VlcTabs &vt, uint32_t cbp_map, uint32_t lane,
 							   : st <= 9 ? 2u
 								     : 4u;
 					} else {
-						if (st >= 4)
+						if (SD_RARE(st >= 4))
 							return -EIO;
 						sub_pm[p] = PM_L0;
 						sub_n[p] = st == 0 ? 1u : st == 3 ? 4u : 2u;
@@ -1950,7 +1956,7 @@ sd_slice_data(WaveBits &wb, const VlcTabs &vt, uint32_t cbp_map, uint32_t lane,
 						if (sub_pm[p] != PM_DIRECT &&
 						    sub_pm[p] != PM_L1) {
 							uint32_t r = vb_te(vb, wb, ref0_range, ok);
-							if (!ok)
+							if (SD_RARE(!ok))
 								return -EIO;
 							lds_w8(stage, 64 + p, r, lane);
 						}
@@ -1961,7 +1967,7 @@ sd_slice_data(WaveBits &wb, const VlcTabs &vt, uint32_t cbp_map, uint32_t lane,
 						if (sub_pm[p] != PM_DIRECT &&
 						    sub_pm[p] != PM_L0) {
 							uint32_t r = vb_te(vb, wb, ref1_range, ok);
-							if (!ok)
+							if (SD_RARE(!ok))
 								return -EIO;
 							lds_w8(stage, 68 + p, r, lane);
 						}
@@ -2009,7 +2015,7 @@ sd_slice_data(WaveBits &wb, const VlcTabs &vt, uint32_t cbp_map, uint32_t lane,
 						for (uint32_t p = 0; p < nparts; p++)
 							if ((p ? pm1 : pm0) != PM_L1) {
 								uint32_t r = vb_te(vb, wb, ref0_range, ok);
-								if (!ok)
+								if (SD_RARE(!ok))
 									return -EIO;
 								lds_w8(stage, 64 + p, r, lane);
 							}
@@ -2018,7 +2024,7 @@ sd_slice_data(WaveBits &wb, const VlcTabs &vt, uint32_t cbp_map, uint32_t lane,
 						for (uint32_t p = 0; p < nparts; p++)
 							if ((p ? pm1 : pm0) != PM_L0) {
 								uint32_t r = vb_te(vb, wb, ref1_range, ok);
-								if (!ok)
+								if (SD_RARE(!ok))
 									return -EIO;
 								lds_w8(stage, 68 + p, r, lane);
 							}
@@ -2045,7 +2051,7 @@ sd_slice_data(WaveBits &wb, const VlcTabs &vt, uint32_t cbp_map, uint32_t lane,
 				 * intra, inter */
 				uint32_t code;
 				VRD_UE(code);
-				if (cat > 3 || code >= (chroma12 ? 48u : 16u))
+				if (SD_RARE(cat > 3 || code >= (chroma12 ? 48u : 16u)))
 					return -EIO;
 				bool intra_col = mb_type == H264_MB_TYPE_I_NxN ||
 						 mb_type == H264_MB_TYPE_SI;
@@ -2065,7 +2071,7 @@ sd_slice_data(WaveBits &wb, const VlcTabs &vt, uint32_t cbp_map, uint32_t lane,
 				}
 			}
 			SD_T(3);
-			if (cbp_luma > 0 || cbp_chroma > 0 || pm0 == PM_I16x16) {
+			if (SD_USUAL(cbp_luma > 0 || cbp_chroma > 0 || pm0 == PM_I16x16)) {
 				VRD_SE(qpd);
 				/* ---- residual (:334-419).  The coded blocks
 				 * are the set bits of `todo` (bit = step, in
@@ -2102,6 +2108,9 @@ sd_slice_data(WaveBits &wb, const VlcTabs &vt, uint32_t cbp_map, uint32_t lane,
 					 * (a parked DC count), nC >= 8 or a chroma DC
 					 * block ends the run. */
 					uint32_t peek = vb_peek(vb);
+					/* (one block in three starts with a 1 bit: no
+					 * hint -- out of line this pass pays two taken
+					 * branches, measured slower) */
 					if (vb_true((int32_t)peek < 0)) {
 						uint32_t ncv = sd_nc_all(m);
 						uint32_t lb = ncv < 2u ? 1u : ncv < 4u ? 2u
@@ -2159,12 +2168,12 @@ sd_slice_data(WaveBits &wb, const VlcTabs &vt, uint32_t cbp_map, uint32_t lane,
 					sd_nz_set(m, nzlane, tc, lane);
 					SD_T(12);
 				}
-				if (__builtin_expect(serr != 0, 0))
+				if (SD_RARE(serr != 0))
 					return -EIO;
 			}
 		}
 		vb_store(vb, wb);
-		if (__builtin_expect(wb_overrun(wb), 0))
+		if (SD_RARE(wb_overrun(wb)))
 			return -EIO;
 		SD_T(13);
 
