@@ -1082,7 +1082,10 @@ sd_residual_block(VBits &vb, WaveBits &wb, const VlcTabs &vt, uint32_t lane,
 		 * VCC with its wait states before the select */
 		uint64_t imask = 1ull << i;
 		const uint64_t iend = 1ull << tc; /* tc <= 16 */
-		for (; imask != iend; imask <<= 1) {
+		/* (a guarded do-while with the guard marked usual: the loop then sits
+		 * in line behind the first level, and the way through it needs no
+		 * jump in and no jump out) */
+		if (SD_USUAL(imask != iend)) do {
 			/* (raw peek: the test below is a 32-bit one already) */
 			uint32_t b1 = (uint32_t)((vb.W << vb.vo) >> 32);
 			/* (as asm: the optimiser reads "p >= 3" below through a
@@ -1135,7 +1138,7 @@ sd_residual_block(VBits &vb, WaveBits &wb, const VlcTabs &vt, uint32_t lane,
 			asm("v_cndmask_b32 %0, %0, %1, %2"
 			    : "+v"(codes)
 			    : "v"(code), "s"(imask));
-		}
+		} while ((imask <<= 1) != iend);
 		i = tc;
 	}
 	SD_T(5);
@@ -1169,9 +1172,9 @@ sd_residual_block(VBits &vb, WaveBits &wb, const VlcTabs &vt, uint32_t lane,
 	/* (loop conditions as ONE compare of a minimum: "runs still to read and
 	 * zeros still to place") */
 	uint32_t left = tc - 1u;
-	while ((left < zeros_left ? left : zeros_left) != 0u) {
+	if (SD_USUAL((left < zeros_left ? left : zeros_left) != 0u)) do {
 		vb_norm(vb, wb);
-		if (zeros_left > 6) {
+		if (SD_RARE(zeros_left > 6)) {
 			zl = wb_setlane(zl, i, zeros_left, lane);
 			uint32_t sb = vb_peek_s(vb);
 			uint32_t t3 = sb >> 29;
@@ -1209,7 +1212,7 @@ sd_residual_block(VBits &vb, WaveBits &wb, const VlcTabs &vt, uint32_t lane,
 			batch--;
 		} while ((batch < zeros_left ? batch : zeros_left) != 0u);
 		left += batch;
-	}
+	} while ((left < zeros_left ? left : zeros_left) != 0u);
 	zl = wb_setlane(zl, tc - 1u, zeros_left, lane);
 	SD_T(7);
 	/* ---- levelCode -> value (even code -> +(code + 2) / 2, odd ->
