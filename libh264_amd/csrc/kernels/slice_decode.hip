@@ -1149,7 +1149,10 @@ sd_residual_block(VBits &vb, WaveBits &wb, const VlcTabs &vt, uint32_t lane,
 	uint32_t zl = 0;
 	uint32_t zeros_left = 0;
 	if (SD_USUAL(tc < maxnum)) {
-		vb_norm(vb, wb);
+		/* no vb_norm() here: vo <= 50 on every way in (behind the token and
+		 * the trailing ones 31 + 16 + 3, behind the first level 31 + 16,
+		 * behind the loop 43, behind an escape 31), and a total_zeros code
+		 * word has 9 bits at most */
 		uint32_t b1 = vb_peek(vb);
 		/* 1 <= tc < maxnum and maxnum in {4, 8, 15, 16} (the callers' block
 		 * constants) keep k inside the 25 tables */
@@ -1174,7 +1177,7 @@ sd_residual_block(VBits &vb, WaveBits &wb, const VlcTabs &vt, uint32_t lane,
 	uint32_t left = tc - 1u;
 	if (SD_USUAL((left < zeros_left ? left : zeros_left) != 0u)) do {
 		vb_norm(vb, wb);
-		if (SD_RARE(zeros_left > 6)) {
+		if (zeros_left > 6) {
 			zl = wb_setlane(zl, i, zeros_left, lane);
 			uint32_t sb = vb_peek_s(vb);
 			uint32_t t3 = sb >> 29;
