@@ -1088,12 +1088,7 @@ sd_residual_block(VBits &vb, WaveBits &wb, const VlcTabs &vt, uint32_t lane,
 		if (SD_USUAL(imask != iend)) do {
 			/* (raw peek: the test below is a 32-bit one already) */
 			uint32_t b1 = (uint32_t)((vb.W << vb.vo) >> 32);
-			/* (as asm: the optimiser reads "p >= 3" below through a
-			 * count of leading zeros as a 64-bit compare of the
-			 * shifted window with a constant, for which the kernel
-			 * has no scalar registers left) */
-			uint32_t p;
-			asm("v_ffbh_u32 %0, %1" : "=v"(p) : "v"(b1 | 0x10000u));
+			uint32_t p = (uint32_t)__builtin_clz(b1 | 0x10000u);
 			uint32_t n = p + 1u + sl;
 			/* vo >= 44 behind the level: step.  p >= 15: vo is 17 at
 			 * least and vo + 2 p >= 44 as well; a smaller p that
@@ -1133,7 +1128,12 @@ sd_residual_block(VBits &vb, WaveBits &wb, const VlcTabs &vt, uint32_t lane,
 				continue;
 			}
 			uint32_t code = (p << sl) + __builtin_amdgcn_ubfe(b1, 32u - n, sl);
-			uint32_t grown = sl + (p >= 3u ? 1u : 0u);
+			/* + 1 iff p >= 3, as bit p of 0xfff8: a compare would put
+			 * the carry through VCC with its wait states (and the
+			 * optimiser reads "p >= 3" through the count of leading
+			 * zeros as a 64-bit compare of the shifted window with a
+			 * constant in spilled scalar registers) */
+			uint32_t grown = sl + ((0xfff8u >> p) & 1u);
 			sl = grown < 6u ? grown : 6u;
 			asm("v_cndmask_b32 %0, %0, %1, %2"
 			    : "+v"(codes)
