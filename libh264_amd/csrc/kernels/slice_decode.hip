@@ -2118,20 +2118,27 @@ sd_slice_data(WaveBits &wb, const VlcTabs &vt, uint32_t cbp_map, uint32_t lane,
 					 * hint -- out of line this pass pays two taken
 					 * branches, measured slower) */
 					if (vb_true((int32_t)peek < 0)) {
+						/* 1, 2 or 4 bits for nC < 2, < 4, < 8; anything
+						 * above 32 stands for "ends the run" (nC >= 8,
+						 * a parked count, a chroma DC block).  In
+						 * arithmetic: three compare-select pairs are
+						 * six instructions and as many wait states on
+						 * VCC, which a lone wave pays in full. */
 						uint32_t ncv = sd_nc_all(m);
-						uint32_t lb = ncv < 2u ? 1u : ncv < 4u ? 2u
-							      : ncv < 8u ? 4u : 64u;
-						lb = m.cur == 0u ? lb : 64u;
+						uint32_t k = ncv >> 1;
+						k = k < 2u ? k : 2u;
+						uint32_t lb = (1u << k) | ((ncv >> 3) << 6) |
+							      ((m.cur + 63u) & 64u);
 						uint32_t ls = (uint32_t)__shfl(
 							(int)lb, (int)(vinfo & 63u));
-						ls = ((vinfo >> 11) & 3u) ? 64u : ls;
+						ls |= (vinfo >> 5) & 0xc0u; /* kind << 6 */
 						uint32_t in_todo =
 							(uint32_t)(todo >> lane) & 1u;
 						uint32_t incl = sd_scan_add(in_todo ? ls : 0u);
 						uint32_t ones = (uint32_t)__builtin_clz(
 							~peek | 1u);
-						uint64_t fit = __ballot(in_todo != 0 &&
-									incl <= ones);
+						/* (the lanes "in todo" are the bits of todo) */
+						uint64_t fit = __ballot(incl <= ones) & todo;
 						if (fit) {
 							uint32_t last = 63u - (uint32_t)
 								__builtin_clzll(fit);
