@@ -858,7 +858,11 @@ __device__ __forceinline__ void sd_nz_set(MbCtx &m, uint32_t l, uint32_t tc,
 	 * compare and branch (the scalar port is the scarce one) */
 	uint32_t old = (uint32_t)__builtin_amdgcn_readlane((int)m.cur, (int)l);
 	uint32_t delta = tc - old;
-	m.cur = lane == l ? tc : m.cur;
+	/* m.cur = lane == l ? tc : m.cur, the lane mask from the scalar side (no
+	 * compare into VCC and wait before the select) */
+	asm("v_cndmask_b32 %0, %0, %1, %2"
+	    : "+v"(m.cur)
+	    : "v"(tc), "s"(1ull << (l & 63u)));
 	/* the blocks that have this one as their inner A or B neighbour: one
 	 * shift of the lane's neighbour mask instead of two compare-select pairs */
 	uint32_t bit = (uint32_t)(m.dep >> l);
@@ -879,8 +883,12 @@ __device__ __forceinline__ void sd_nz_set(MbCtx &m, uint32_t l, uint32_t tc,
  * into bytes 8..15 of the staged record and returns the bits consumed. */
 __device__ __forceinline__ uint32_t sd_gather(uint32_t table, uint32_t idx)
 {
+	/* table[i] > i and table[i] <= i + 64 (a jump forward by 1 .. 64 bits):
+	 * the maximum is the entry for idx < 64 and idx itself beyond, where
+	 * the lane wraps -- one instruction where compare and select are two
+	 * and a wait on VCC */
 	uint32_t v = (uint32_t)__shfl((int)table, (int)(idx & 63u));
-	return idx >= 64u ? idx : v;
+	return v > idx ? v : idx;
 }
 
 __device__ __forceinline__ uint32_t sd_intra_pred_modes(const VBits &vb,
@@ -1038,6 +1046,10 @@ sd_residual_block(VBits &vb, WaveBits &wb, const VlcTabs &vt, uint32_t lane,
 		const uint32_t first_adj = 2u * few;
 		const uint32_t sl0 = few & ((10u - tc) >> 31); /* && tc > 10 */
 		uint32_t sl; /* suffixLength, vector side */
+		/* lane i of `codes` takes level i: the lane mask comes from the
+		 * scalar side (one s_lshl_b64 per level) instead of a v_cmp into
+		 * VCC with its wait states before the select */
+		uint64_t imask = 1ull << i;
 		vb_norm(vb, wb);
 		{
 			uint32_t b1 = vb_peek(vb);
@@ -1065,10 +1077,12 @@ sd_residual_block(VBits &vb, WaveBits &wb, const VlcTabs &vt, uint32_t lane,
 				/* suffixLength becomes 1, and 2 when the magnitude
 				 * (code + 2) >> 1 exceeds 3 */
 				sl = code >= 6u ? 2u : 1u;
-				codes = lane == i ? code : codes;
+				asm("v_cndmask_b32 %0, %0, %1, %2"
+				    : "+v"(codes)
+				    : "v"(code), "s"(imask));
 			}
 		}
-		i++;
+		imask <<= 1;
 		/* every later level finds 1 <= suffixLength <= 6 and no adjustment:
 		 * levelCode lies below 3 << suffixLength exactly when prefix < 3, so
 		 * suffixLength grows iff prefix >= 3 -- no magnitude needed */
@@ -1077,10 +1091,6 @@ sd_residual_block(VBits &vb, WaveBits &wb, const VlcTabs &vt, uint32_t lane,
 		 * rare events, the escape (prefix >= 15) and the window step: the
 		 * usual updates are applied first and an escape takes them back. */
 		vb_norm(vb, wb);
-		/* lane i of `codes` takes the level: the lane mask comes from the
-		 * scalar side (one s_lshl_b64 per level) instead of a v_cmp into
-		 * VCC with its wait states before the select */
-		uint64_t imask = 1ull << i;
 		const uint64_t iend = 1ull << tc; /* tc <= 16 */
 		/* (a guarded do-while with the guard marked usual: the loop then sits
 		 * in line behind the first level, and the way through it needs no
