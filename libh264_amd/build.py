@@ -97,10 +97,16 @@ def build_engine(force=False):
         # flow is wave-uniform by construction; without the flag the backend
         # still threads uniform regions through the structurizer's flow blocks
         # (s_mov -1 / s_andn2 vcc, exec / s_cbranch_vccnz chains): 17 % more
-        # scalar instructions, 4 % more time (profiles/r02_decode_cost_model.md)
+        # scalar instructions, 4 % more time (profiles/r02_decode_cost_model.md).
+        # -O2 with the unroll threshold of -O3: the pick of six optimiser
+        # settings timed at the end of round 3 (profiles/r03_decode_ab_history.jsonl);
+        # they lie within 2 % of each other and trade I slices against P / B:
+        # this one is the fastest on I slices (4096: 50.2 ms against 51.0 with
+        # -O3, a lone wave 40.8 against 42.0) and 3 % slower than -O3 on the
+        # mixed I / P stream of config 4.
         opt = os.environ.get(
             "H264_AMD_HIPCC_OPT",
-            "-O3 -mllvm -structurizecfg-skip-uniform-regions").split()
+            "-O2 -mllvm -unroll-threshold=300 -mllvm -structurizecfg-skip-uniform-regions").split()
         _run([_hipcc(), "--offload-arch=gfx950"] + opt + ["-std=c++17", "-fPIC",
               "-shared", "-Wno-unused-value", "-Wno-inline-asm", "-I" + INC, "-I" + CSRC,
               '-DH264_AMD_BUILD_ID="%s"' % sid,
